@@ -1,0 +1,141 @@
+/*
+ * lva_decoder.h -- C ABI of the MI355X list-Viterbi decoder (liblva_hip.so).
+ *
+ * Drop-in boundary for ONE path of shubhamchandak94/nanopore_dna_storage: the
+ * convolutional-code parallel list-Viterbi decode of a flappie transition-posterior
+ * matrix.  The reference has no library API for this path -- its boundary is the
+ * subprocess `viterbi_nanopore.out -m decode -i X.post -o OUT ...` -- so each entry
+ * point below cites the reference code it replaces
+ * (file viterbi/viterbi_convolutional_code.cpp unless stated otherwise).
+ *
+ * Plain C types only: pointers, sizes, POD structs.  No torch / HIP types.
+ * All functions return LVA_OK (0) or a negative LVA_ERR_* code; none aborts.
+ */
+#ifndef LVA_DECODER_H
+#define LVA_DECODER_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LVA_OK 0
+#define LVA_ERR_MEM_CONV (-1)        /* "Invalid mem_conv (allowed: 6, 8, 11, 14)"      :290-292 */
+#define LVA_ERR_RATE (-2)            /* "Invalid rate parameter"                        :336-338 */
+#define LVA_ERR_MSG_LEN (-3)         /* "Output length not even. Try padding ..."       :353-357 */
+#define LVA_ERR_SYNC (-4)            /* sync marker too long / period short / bad char  :390-413 */
+#define LVA_ERR_TOO_MANY_STATES (-5) /* runtime_error "Too many states"                 :595-597 */
+#define LVA_ERR_POST_TOO_SHORT (-6)  /* runtime_error "Too small post matrix"           :600-601 */
+#define LVA_ERR_MSG_TOO_LONG (-7)    /* runtime_error msg_len > BITSET_SIZE :604-605; uint8_t loop :831 */
+#define LVA_ERR_NOMEM (-8)
+#define LVA_ERR_HIP (-9)             /* a HIP runtime call failed (lva_last_hip_error has the text) */
+#define LVA_ERR_ARG (-10)
+#define LVA_ERR_NO_DEVICE (-11)      /* no gfx950 device visible: the product never falls back to CPU */
+#define LVA_ERR_UNSUPPORTED (-12)
+
+#define LVA_MAX_DEVIATION_DEFAULT 0xFFFFFFFFu /* reference default msg_len+mem_conv+1 (:238-240) */
+
+typedef struct lva_decoder lva_decoder;
+
+/* Decoder configuration = the decode-side CLI flags of the reference (:138-172):
+ *   --mem-conv, -r/--rate, --msg-len, -l/--list-size, --max-deviation,
+ *   --sync-marker, --sync-period.  (-t/--num-thr has no meaning on the GPU;
+ *   --rc is per read, see lva_decode_batch.) */
+typedef struct lva_config {
+  int32_t mem_conv;
+  int32_t rate;
+  uint32_t msg_len;
+  uint32_t list_size;
+  uint32_t max_deviation;   /* LVA_MAX_DEVIATION_DEFAULT = unbanded */
+  const char *sync_marker;  /* NULL or "" = none */
+  uint32_t sync_period;
+  int32_t device;           /* HIP device ordinal */
+  int32_t max_slots;        /* reads in flight on the device; 0 = choose from free HBM */
+  int32_t kernel;           /* 0 = default; 1 = exact kernel only; 2 = fast kernel + exact fix-up */
+  uint64_t mem_budget_bytes;/* cap on trellis memory; 0 = 60% of free HBM */
+} lva_config;
+
+/* Static facts about a code (set_conv_params :264-415). */
+typedef struct lva_code_info {
+  uint32_t nstate_pos, nstate_conv, oligo_len, msg_words;
+  uint32_t initial_state, final_state;
+  uint32_t g0, g1;
+  int32_t pattern_len;
+  uint8_t pattern[16];
+} lva_code_info;
+
+/* Counters of the last lva_decode_batch* call (bench.py's roofline object). */
+typedef struct lva_profile {
+  double step_kernel_ms;      /* HIP-event time from first to last trellis-step launch, on the decoder's stream */
+  double total_ms;            /* HIP-event time of the whole call's device work (upload..results) */
+  uint64_t step_launches;     /* trellis-step kernel launches */
+  uint64_t read_steps;        /* sum over reads of nblk (one launch advances every active read one step) */
+  double algorithmic_bytes;   /* sum over reads of sum_t [2 R(t) L (4+4W) + 160] */
+  uint64_t fixup_states;      /* states redone by the exact kernel (kernel mode 2) */
+  int32_t slots;              /* reads in flight */
+  int32_t kernel;             /* kernel mode used */
+} lva_profile;
+
+const char *lva_version(void);
+const char *lva_strerror(int code);
+const char *lva_last_hip_error(void);
+
+/* --- host-only: code parameters and the encoder ------------------------------------------- */
+
+/* set_conv_params (:264-415): validate and describe a code. */
+int lva_code_describe(int32_t mem_conv, int32_t rate, uint32_t msg_len, int32_t rc,
+                      const char *sync_marker, uint32_t sync_period, lva_code_info *out);
+
+/* The tables the kernels use, for inspection/tests.  Each output may be NULL.
+ *   pos2msg[nstate_pos], ptype[nstate_pos], vmask[nstate_pos], vval[nstate_pos],
+ *   predtab[4][nstate_conv] (uint16, zero rows for unused block types). */
+int lva_code_tables(int32_t mem_conv, int32_t rate, uint32_t msg_len, int32_t rc,
+                    const char *sync_marker, uint32_t sync_period, uint32_t *pos2msg, uint8_t *ptype,
+                    uint32_t *vmask, uint32_t *vval, uint16_t *predtab);
+
+/* `-m encode` (:215-225): conv_encode (:450-499) + 2-bit base packing (:540-551).
+ * msgs: n_msgs*msg_len bytes of 0/1.  out_bases: n_msgs*oligo_len bytes, values 0..3 = A,C,G,T. */
+int lva_encode(int32_t mem_conv, int32_t rate, uint32_t msg_len, const uint8_t *msgs, int32_t n_msgs,
+               uint8_t *out_bases);
+
+/* SURVEY 8(d) algorithmic bytes of one read of nblk blocks. */
+int lva_algorithmic_bytes(int32_t mem_conv, int32_t rate, uint32_t msg_len, int32_t rc,
+                          const char *sync_marker, uint32_t sync_period, uint32_t nblk,
+                          uint32_t list_size, uint32_t max_deviation, double *out);
+
+/* --- decoder ------------------------------------------------------------------------------ */
+
+/* Replaces process start-up of `viterbi_nanopore.out -m decode` (main :137-214, set_conv_params,
+ * table construction :624-650).  Fails with LVA_ERR_NO_DEVICE when no GPU is usable. */
+int lva_decoder_create(const lva_config *cfg, lva_decoder **out);
+void lva_decoder_destroy(lva_decoder *d);
+
+/* Replaces read_crf_post (:553-575) + decode_post_conv_parallel_LVA (:589-858) + the list
+ * writer (:248-253) for n_reads independent reads.
+ *   post         host float32, all reads' .post matrices back to back, 40 floats per block
+ *                (file order: rows 0-3 = into flip base b from state s at [b*8+s], row 4 = into flop);
+ *   row_offsets  n_reads+1 block offsets into post (read i = blocks [off[i], off[i+1]));
+ *   rc_flags     n_reads bytes, 1 = decode as reverse complement (--rc), NULL = all forward;
+ *   out_msgs     n_reads*list_size*msg_len bytes of 0/1, best first (rows >= count untouched);
+ *   out_scores   n_reads*list_size path scores (may be NULL);
+ *   out_counts   n_reads: number of list entries (<= list_size), or a negative LVA_ERR_* for a
+ *                read the reference would have thrown on (e.g. LVA_ERR_POST_TOO_SHORT). */
+int lva_decode_batch(lva_decoder *d, const float *post, const int64_t *row_offsets, int32_t n_reads,
+                     const uint8_t *rc_flags, uint8_t *out_msgs, float *out_scores, int32_t *out_counts);
+
+/* Same, with `post` already resident in device memory (HBM) of the decoder's device. */
+int lva_decode_batch_device(lva_decoder *d, const float *post_dev, const int64_t *row_offsets,
+                            int32_t n_reads, const uint8_t *rc_flags, uint8_t *out_msgs,
+                            float *out_scores, int32_t *out_counts);
+
+int lva_decoder_profile(const lva_decoder *d, lva_profile *out);
+
+/* Device helpers so that callers without a HIP binding (ctypes) can keep inputs resident. */
+int lva_device_alloc(lva_decoder *d, uint64_t bytes, void **out_dev_ptr);
+int lva_device_free(lva_decoder *d, void *dev_ptr);
+int lva_device_upload(lva_decoder *d, void *dev_dst, const void *host_src, uint64_t bytes);
+int lva_device_synchronize(lva_decoder *d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

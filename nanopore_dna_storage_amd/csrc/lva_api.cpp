@@ -1,0 +1,433 @@
+// lva_api.cpp -- C ABI (include/lva_decoder.h) and the host driver of the trellis kernels.
+//
+// Scheduling: reads are independent.  The decoder keeps S read slots resident in
+// HBM; one trellis-step launch advances every active slot by one time step of its own read,
+// so reads of different lengths overlap freely: a slot whose read finishes is gathered and
+// re-initialised for the next read while the others continue ("continuous batching" of the
+// reference's sequential time loop :667).  Everything is enqueued on one HIP stream without
+// host synchronisation until the results are copied back.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/lva_decoder.h"
+#include "lva_code.h"
+#include "lva_device.h"
+#include "lva_kernels.h"
+
+using namespace lva;
+
+namespace {
+
+thread_local std::string g_hip_error;
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e__ = (expr);                                                                   \
+    if (e__ != hipSuccess) {                                                                   \
+      g_hip_error = std::string(#expr) + ": " + hipGetErrorString(e__);                        \
+      return LVA_ERR_HIP;                                                                      \
+    }                                                                                          \
+  } while (0)
+
+}  // namespace
+
+struct lva_decoder {
+  lva_config cfg{};
+  std::string sync_marker;
+  Code code[2];                // forward, reverse complement
+  uint32_t max_dev = 0;
+  Geometry g{};
+  int slots = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_total0 = nullptr, ev_total1 = nullptr, ev_step0 = nullptr, ev_step1 = nullptr;
+  DevCode* d_codes = nullptr;
+  uint16_t* d_predtab = nullptr;
+  uint32_t* d_trellis = nullptr;
+  uint32_t* d_results = nullptr;
+  size_t results_cap = 0;      // reads
+  lva_profile prof{};
+};
+
+extern "C" {
+
+const char* lva_version(void) { return "lva_hip 0.1 (gfx950)"; }
+
+const char* lva_last_hip_error(void) { return g_hip_error.c_str(); }
+
+const char* lva_strerror(int code) {
+  switch (code) {
+    case LVA_OK: return "ok";
+    case LVA_ERR_MEM_CONV: return "Invalid mem_conv (allowed: 6, 8, 11, 14)";
+    case LVA_ERR_RATE: return "Invalid rate parameter (allowed: 1, 2, 3, 4, 5, 7)";
+    case LVA_ERR_MSG_LEN: return "Output length not even. Try padding with a single 0 at end.";
+    case LVA_ERR_SYNC: return "Invalid sync marker / sync period";
+    case LVA_ERR_TOO_MANY_STATES: return "Too many states, can't fit in 32 bits";
+    case LVA_ERR_POST_TOO_SHORT: return "Too small post matrix";
+    case LVA_ERR_MSG_TOO_LONG: return "msg_len too large (message + memory must fit 256 bits, msg_len <= 255)";
+    case LVA_ERR_NOMEM: return "out of memory";
+    case LVA_ERR_HIP: return "HIP runtime error";
+    case LVA_ERR_ARG: return "invalid argument";
+    case LVA_ERR_NO_DEVICE: return "no usable HIP device (the decoder has no CPU fallback)";
+    case LVA_ERR_UNSUPPORTED: return "unsupported code structure";
+    default: return "unknown error";
+  }
+}
+
+int lva_code_describe(int32_t mem_conv, int32_t rate, uint32_t msg_len, int32_t rc, const char* sync_marker,
+                      uint32_t sync_period, lva_code_info* out) {
+  Code c;
+  const int st = build_code(&c, mem_conv, rate, msg_len, rc, sync_marker, sync_period);
+  if (st != LVA_OK) return st;
+  if (!out) return LVA_OK;
+  std::memset(out, 0, sizeof *out);
+  out->nstate_pos = c.npos; out->nstate_conv = c.nconv; out->oligo_len = c.oligo_len();
+  out->msg_words = c.msg_words(); out->initial_state = c.init; out->final_state = c.fin;
+  out->g0 = c.g[0]; out->g1 = c.g[1]; out->pattern_len = c.plen;
+  std::memcpy(out->pattern, c.pattern, 16);
+  return LVA_OK;
+}
+
+int lva_code_tables(int32_t mem_conv, int32_t rate, uint32_t msg_len, int32_t rc, const char* sync_marker,
+                    uint32_t sync_period, uint32_t* pos2msg, uint8_t* ptype, uint32_t* vmask, uint32_t* vval,
+                    uint16_t* predtab) {
+  Code c;
+  const int st = build_code(&c, mem_conv, rate, msg_len, rc, sync_marker, sync_period);
+  if (st != LVA_OK) return st;
+  if (pos2msg) std::memcpy(pos2msg, c.pos2msg, c.npos * sizeof(uint32_t));
+  if (ptype) std::memcpy(ptype, c.ptype, c.npos);
+  if (vmask) std::memcpy(vmask, c.vmask, c.npos * sizeof(uint32_t));
+  if (vval) std::memcpy(vval, c.vval, c.npos * sizeof(uint32_t));
+  if (predtab)
+    for (int T = 0; T < 4; ++T) {
+      uint16_t* dst = predtab + (size_t)T * c.nconv;
+      if (c.predtab[T].empty()) std::memset(dst, 0, c.nconv * sizeof(uint16_t));
+      else std::memcpy(dst, c.predtab[T].data(), c.nconv * sizeof(uint16_t));
+    }
+  return LVA_OK;
+}
+
+int lva_encode(int32_t mem_conv, int32_t rate, uint32_t msg_len, const uint8_t* msgs, int32_t n_msgs,
+               uint8_t* out_bases) {
+  if (n_msgs < 0 || (n_msgs > 0 && (!msgs || !out_bases))) return LVA_ERR_ARG;
+  Code c;
+  const int st = build_code(&c, mem_conv, rate, msg_len, 0, nullptr, 0);
+  if (st != LVA_OK) return st;
+  for (int32_t i = 0; i < n_msgs; ++i) {
+    const int e = c.encode(msgs + (size_t)i * msg_len, out_bases + (size_t)i * c.oligo_len());
+    if (e != LVA_OK) return e;
+  }
+  return LVA_OK;
+}
+
+int lva_algorithmic_bytes(int32_t mem_conv, int32_t rate, uint32_t msg_len, int32_t rc, const char* sync_marker,
+                          uint32_t sync_period, uint32_t nblk, uint32_t list_size, uint32_t max_deviation,
+                          double* out) {
+  Code c;
+  const int st = build_code(&c, mem_conv, rate, msg_len, rc, sync_marker, sync_period);
+  if (st != LVA_OK) return st;
+  if (max_deviation == LVA_MAX_DEVIATION_DEFAULT) max_deviation = msg_len + (uint32_t)mem_conv + 1;
+  if (out) *out = c.algorithmic_bytes(nblk, list_size, max_deviation);
+  return LVA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+
+static int upload_codes(lva_decoder* d) {
+  // predecessor tables of both orientations in one allocation: [orient 2][type 4][nconv]
+  const uint32_t N = d->code[0].nconv;
+  std::vector<uint16_t> host((size_t)2 * 4 * N, 0);
+  for (int o = 0; o < 2; ++o)
+    for (int T = 0; T < 4; ++T)
+      if (!d->code[o].predtab[T].empty())
+        std::memcpy(host.data() + ((size_t)o * 4 + T) * N, d->code[o].predtab[T].data(), N * sizeof(uint16_t));
+  HIP_TRY(hipMalloc(&d->d_predtab, host.size() * sizeof(uint16_t)));
+  HIP_TRY(hipMemcpy(d->d_predtab, host.data(), host.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  DevCode dc[2];
+  std::memset(dc, 0, sizeof dc);
+  for (int o = 0; o < 2; ++o) {
+    const Code& c = d->code[o];
+    dc[o].m = (uint32_t)c.mem_conv; dc[o].nconv = c.nconv; dc[o].npos = c.npos; dc[o].init = c.init; dc[o].fin = c.fin;
+    std::memcpy(dc[o].ptype, c.ptype, sizeof dc[o].ptype);
+    std::memcpy(dc[o].vmask, c.vmask, sizeof dc[o].vmask);
+    std::memcpy(dc[o].vval, c.vval, sizeof dc[o].vval);
+    for (int T = 0; T < 4; ++T)
+      dc[o].predtab[T] = c.predtab[T].empty() ? nullptr : d->d_predtab + ((size_t)o * 4 + T) * N;
+  }
+  HIP_TRY(hipMalloc(&d->d_codes, sizeof dc));
+  HIP_TRY(hipMemcpy(d->d_codes, dc, sizeof dc, hipMemcpyHostToDevice));
+  return LVA_OK;
+}
+
+int lva_decoder_create(const lva_config* cfg, lva_decoder** out) {
+  if (!cfg || !out) return LVA_ERR_ARG;
+  *out = nullptr;
+  if (cfg->list_size == 0 || cfg->list_size > 65535) return LVA_ERR_ARG;
+  lva_decoder* d = new (std::nothrow) lva_decoder();
+  if (!d) return LVA_ERR_NOMEM;
+  d->cfg = *cfg;
+  d->sync_marker = cfg->sync_marker ? cfg->sync_marker : "";
+  d->cfg.sync_marker = nullptr;
+  for (int o = 0; o < 2; ++o) {
+    const int st = build_code(&d->code[o], cfg->mem_conv, cfg->rate, cfg->msg_len, o, d->sync_marker.c_str(),
+                              cfg->sync_period);
+    if (st != LVA_OK) { delete d; return st; }
+  }
+  const Code& c = d->code[0];
+  if (c.msg_len > 255 || c.msg_len + (uint32_t)c.mem_conv > 256) { delete d; return LVA_ERR_MSG_TOO_LONG; }
+  if ((uint64_t)c.npos * kCrf * c.nconv >= ((uint64_t)1 << 32)) { delete d; return LVA_ERR_TOO_MANY_STATES; }
+  d->max_dev = cfg->max_deviation == LVA_MAX_DEVIATION_DEFAULT ? c.msg_len + (uint32_t)c.mem_conv + 1 : cfg->max_deviation;
+  const uint64_t ring = std::min<uint64_t>(c.npos, 2ull * d->max_dev + 1);
+  d->g = make_geometry(c.nconv, cfg->list_size, c.msg_words(), (uint32_t)std::max<uint64_t>(ring, 1));
+  if (d->g.sPar >= ((uint64_t)1 << 32)) { delete d; return LVA_ERR_TOO_MANY_STATES; }
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
+    delete d;
+    return LVA_ERR_NO_DEVICE;
+  }
+  d->device = cfg->device;
+  auto fail = [&](int code) { lva_decoder_destroy(d); return code; };
+  if (hipSetDevice(d->device) != hipSuccess) return fail(LVA_ERR_NO_DEVICE);
+  if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) return fail(LVA_ERR_HIP);
+  hipEventCreate(&d->ev_total0); hipEventCreate(&d->ev_total1);
+  hipEventCreate(&d->ev_step0); hipEventCreate(&d->ev_step1);
+  {
+    const int st = upload_codes(d);
+    if (st != LVA_OK) return fail(st);
+  }
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return fail(LVA_ERR_HIP);
+  const uint64_t slot_bytes = d->g.sSlot * sizeof(uint32_t);
+  uint64_t budget = cfg->mem_budget_bytes ? cfg->mem_budget_bytes : (uint64_t)(free_b * 0.6);
+  int slots = (int)std::min<uint64_t>(budget / slot_bytes, kMaxSlots);
+  if (cfg->max_slots > 0) slots = std::min(slots, (int)cfg->max_slots);
+  else slots = std::min(slots, 32);
+  if (slots < 1) return fail(LVA_ERR_NOMEM);
+  d->slots = slots;
+  if (hipMalloc(&d->d_trellis, (size_t)slots * slot_bytes) != hipSuccess) return fail(LVA_ERR_NOMEM);
+  d->prof.slots = slots;
+  d->prof.kernel = cfg->kernel == 0 ? 1 : cfg->kernel;
+  *out = d;
+  return LVA_OK;
+}
+
+void lva_decoder_destroy(lva_decoder* d) {
+  if (!d) return;
+  hipSetDevice(d->device);
+  if (d->stream) hipStreamSynchronize(d->stream);
+  if (d->d_trellis) hipFree(d->d_trellis);
+  if (d->d_results) hipFree(d->d_results);
+  if (d->d_codes) hipFree(d->d_codes);
+  if (d->d_predtab) hipFree(d->d_predtab);
+  if (d->ev_total0) hipEventDestroy(d->ev_total0);
+  if (d->ev_total1) hipEventDestroy(d->ev_total1);
+  if (d->ev_step0) hipEventDestroy(d->ev_step0);
+  if (d->ev_step1) hipEventDestroy(d->ev_step1);
+  if (d->stream) hipStreamDestroy(d->stream);
+  delete d;
+}
+
+int lva_decoder_profile(const lva_decoder* d, lva_profile* out) {
+  if (!d || !out) return LVA_ERR_ARG;
+  *out = d->prof;
+  return LVA_OK;
+}
+
+// final selection (:806-844) on the host: gather finite entries crf-major, std::sort by score
+// descending (the same libstdc++ algorithm the reference calls), keep list_size, unpack bits
+static void finish_read(const lva_decoder* d, int orient, const uint32_t* rec, uint8_t* out_msgs, float* out_scores,
+                        int32_t* out_count) {
+  struct Path { float score; const uint32_t* words; };
+  const uint32_t L = d->g.L, F = d->g.F;
+  const Code& c = d->code[orient];
+  std::vector<Path> paths;
+  paths.reserve((size_t)8 * L);
+  const float NEG = -std::numeric_limits<float>::infinity();
+  for (uint32_t k = 0; k < 8; ++k)
+    for (uint32_t l = 0; l < L; ++l) {
+      const uint32_t* e = rec + ((size_t)k * L + l) * F;
+      float s;
+      std::memcpy(&s, e, sizeof s);
+      if (s != NEG) paths.push_back({s, e + 2});
+    }
+  std::sort(paths.begin(), paths.end(), [](const Path& a, const Path& b) -> bool { return a.score > b.score; });
+  if (paths.size() > L) paths.resize(L);
+  const uint32_t total = c.msg_len + (uint32_t)c.mem_conv;
+  for (size_t i = 0; i < paths.size(); ++i) {
+    uint8_t* o = out_msgs + i * c.msg_len;
+    for (uint32_t b = 0; b < c.msg_len; ++b) {
+      const uint32_t bit = total - 1 - b;                              // :831-834
+      const uint8_t v = (uint8_t)((paths[i].words[bit >> 5] >> (bit & 31)) & 1u);
+      o[c.rc ? c.msg_len - 1 - b : b] = v;                             // :835
+    }
+    if (out_scores) out_scores[i] = paths[i].score;
+  }
+  *out_count = (int32_t)paths.size();
+}
+
+static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* off, int32_t n, const uint8_t* rc_flags,
+                       uint8_t* out_msgs, float* out_scores, int32_t* out_counts, bool timed_total_started) {
+  const Geometry& g = d->g;
+  const uint32_t npos = d->code[0].npos, L = g.L;
+  const size_t rec_words = (size_t)8 * L * g.F;
+  // reads the reference would refuse (:600-601)
+  std::vector<int32_t> order;
+  for (int32_t i = 0; i < n; ++i) {
+    const int64_t nb = off[i + 1] - off[i];
+    if (nb < 0 || nb > 0xFFFFFFFFll) return LVA_ERR_ARG;
+    if ((uint64_t)nb < (uint64_t)npos + 1) out_counts[i] = LVA_ERR_POST_TOO_SHORT;
+    else { out_counts[i] = 0; order.push_back(i); }
+  }
+  // longest first: the tail of the schedule is then made of short reads
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return off[a + 1] - off[a] > off[b + 1] - off[b]; });
+
+  if ((size_t)n > d->results_cap) {
+    if (d->d_results) hipFree(d->d_results);
+    d->d_results = nullptr;
+    HIP_TRY(hipMalloc(&d->d_results, (size_t)n * rec_words * sizeof(uint32_t)));
+    d->results_cap = (size_t)n;
+  }
+  if (!timed_total_started) HIP_TRY(hipEventRecord(d->ev_total0, d->stream));
+
+  struct Slot { int32_t read = -1; uint32_t t = 0, nblk = 0, orient = 0, prev_hi = 1; };
+  std::vector<Slot> slot((size_t)std::min<size_t>((size_t)d->slots, std::max<size_t>(order.size(), 1)));
+  size_t next = 0;
+  std::vector<uint8_t> gathered((size_t)n, 0);
+  d->prof.step_launches = 0; d->prof.read_steps = 0; d->prof.algorithmic_bytes = 0; d->prof.fixup_states = 0;
+  bool first_step = true;
+  size_t active = 0;
+  for (;;) {
+    // (re)fill idle slots
+    for (size_t s = 0; s < slot.size(); ++s) {
+      if (slot[s].read >= 0 || next >= order.size()) continue;
+      const int32_t r = order[next++];
+      slot[s].read = r; slot[s].t = 0; slot[s].nblk = (uint32_t)(off[r + 1] - off[r]);
+      slot[s].orient = rc_flags && rc_flags[r] ? 1u : 0u; slot[s].prev_hi = 1;
+      const int e = launch_init_slot(g, d->d_codes, d->d_trellis, (uint32_t)s, slot[s].orient, d->stream);
+      if (e) { g_hip_error = hipGetErrorString((hipError_t)e); return LVA_ERR_HIP; }
+      d->prof.algorithmic_bytes += d->code[slot[s].orient].algorithmic_bytes(slot[s].nblk, L, d->max_dev);
+      ++active;
+    }
+    if (active == 0) break;
+    StepArgs a;
+    a.nslots = 0; a.L = L; a.W = g.W; a.R = g.R; a.band_max = 0; a.pad = 0;
+    for (size_t s = 0; s < slot.size(); ++s) {
+      if (slot[s].read < 0) continue;
+      SlotStep& ss = a.s[a.nslots++];
+      uint32_t lo, hi;
+      d->code[slot[s].orient].band(slot[s].t, slot[s].nblk, d->max_dev, &lo, &hi);
+      ss.post_row = post_dev + ((size_t)off[slot[s].read] + slot[s].t) * 40;
+      ss.slot = (uint32_t)s; ss.t = slot[s].t; ss.lo = lo; ss.hi = hi; ss.prev_hi = slot[s].prev_hi;
+      ss.orient = slot[s].orient;
+      if (hi > lo) a.band_max = std::max(a.band_max, hi - lo);
+      slot[s].prev_hi = hi;   // what step t+1 may read as written
+    }
+    if (first_step) { HIP_TRY(hipEventRecord(d->ev_step0, d->stream)); first_step = false; }
+    {
+      const int e = launch_step_exact(a, g, d->d_codes, d->d_trellis, d->stream);
+      if (e) { g_hip_error = hipGetErrorString((hipError_t)e); return LVA_ERR_HIP; }
+    }
+    d->prof.step_launches += 1;
+    d->prof.read_steps += a.nslots;
+    // retire finished reads
+    for (size_t s = 0; s < slot.size(); ++s) {
+      if (slot[s].read < 0) continue;
+      if (++slot[s].t < slot[s].nblk) continue;
+      uint32_t lo, hi;
+      d->code[slot[s].orient].band(slot[s].nblk - 1, slot[s].nblk, d->max_dev, &lo, &hi);
+      if (lo <= npos - 1 && npos - 1 < hi) {   // otherwise the final state was never written: empty list
+        GatherArgs ga{(uint32_t)s, (uint32_t)(slot[s].nblk & 1u), slot[s].orient, (uint32_t)slot[s].read};
+        const int e = launch_gather_final(g, d->d_codes, d->d_trellis, ga, d->d_results, d->stream);
+        if (e) { g_hip_error = hipGetErrorString((hipError_t)e); return LVA_ERR_HIP; }
+        gathered[(size_t)slot[s].read] = 1;
+      }
+      slot[s].read = -1;
+      --active;
+    }
+  }
+  if (!first_step) HIP_TRY(hipEventRecord(d->ev_step1, d->stream));
+  std::vector<uint32_t> host((size_t)n * rec_words);
+  if (n > 0) HIP_TRY(hipMemcpyAsync(host.data(), d->d_results, host.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipEventRecord(d->ev_total1, d->stream));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  float ms = 0;
+  if (!first_step) { HIP_TRY(hipEventElapsedTime(&ms, d->ev_step0, d->ev_step1)); }
+  d->prof.step_kernel_ms = ms;
+  HIP_TRY(hipEventElapsedTime(&ms, d->ev_total0, d->ev_total1));
+  d->prof.total_ms = ms;
+
+  for (int32_t i = 0; i < n; ++i) {
+    if (out_counts[i] < 0) continue;
+    if (!gathered[(size_t)i]) { out_counts[i] = 0; continue; }
+    finish_read(d, rc_flags && rc_flags[i] ? 1 : 0, host.data() + (size_t)i * rec_words,
+                out_msgs + (size_t)i * L * d->code[0].msg_len, out_scores ? out_scores + (size_t)i * L : nullptr,
+                &out_counts[i]);
+  }
+  return LVA_OK;
+}
+
+int lva_decode_batch_device(lva_decoder* d, const float* post_dev, const int64_t* row_offsets, int32_t n_reads,
+                            const uint8_t* rc_flags, uint8_t* out_msgs, float* out_scores, int32_t* out_counts) {
+  if (!d || n_reads < 0 || !row_offsets || (n_reads > 0 && (!post_dev || !out_msgs || !out_counts))) return LVA_ERR_ARG;
+  if (hipSetDevice(d->device) != hipSuccess) return LVA_ERR_NO_DEVICE;
+  return decode_impl(d, post_dev, row_offsets, n_reads, rc_flags, out_msgs, out_scores, out_counts, false);
+}
+
+int lva_decode_batch(lva_decoder* d, const float* post, const int64_t* row_offsets, int32_t n_reads,
+                     const uint8_t* rc_flags, uint8_t* out_msgs, float* out_scores, int32_t* out_counts) {
+  if (!d || n_reads < 0 || !row_offsets || (n_reads > 0 && (!post || !out_msgs || !out_counts))) return LVA_ERR_ARG;
+  if (hipSetDevice(d->device) != hipSuccess) return LVA_ERR_NO_DEVICE;
+  const int64_t blocks = n_reads > 0 ? row_offsets[n_reads] : 0;
+  if (blocks < 0) return LVA_ERR_ARG;
+  float* dev = nullptr;
+  const size_t bytes = (size_t)std::max<int64_t>(blocks, 1) * 40 * sizeof(float);
+  HIP_TRY(hipMalloc(&dev, bytes));
+  hipError_t e = hipEventRecord(d->ev_total0, d->stream);
+  if (e == hipSuccess && blocks > 0)
+    e = hipMemcpyAsync(dev, post, (size_t)blocks * 40 * sizeof(float), hipMemcpyHostToDevice, d->stream);
+  if (e != hipSuccess) { g_hip_error = hipGetErrorString(e); hipFree(dev); return LVA_ERR_HIP; }
+  const int st = decode_impl(d, dev, row_offsets, n_reads, rc_flags, out_msgs, out_scores, out_counts, true);
+  hipStreamSynchronize(d->stream);
+  hipFree(dev);
+  return st;
+}
+
+int lva_device_alloc(lva_decoder* d, uint64_t bytes, void** out_dev_ptr) {
+  if (!d || !out_dev_ptr) return LVA_ERR_ARG;
+  HIP_TRY(hipSetDevice(d->device));
+  HIP_TRY(hipMalloc(out_dev_ptr, (size_t)std::max<uint64_t>(bytes, 1)));
+  return LVA_OK;
+}
+
+int lva_device_free(lva_decoder* d, void* dev_ptr) {
+  if (!d) return LVA_ERR_ARG;
+  HIP_TRY(hipSetDevice(d->device));
+  HIP_TRY(hipFree(dev_ptr));
+  return LVA_OK;
+}
+
+int lva_device_upload(lva_decoder* d, void* dev_dst, const void* host_src, uint64_t bytes) {
+  if (!d || (bytes && (!dev_dst || !host_src))) return LVA_ERR_ARG;
+  HIP_TRY(hipSetDevice(d->device));
+  HIP_TRY(hipMemcpyAsync(dev_dst, host_src, (size_t)bytes, hipMemcpyHostToDevice, d->stream));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  return LVA_OK;
+}
+
+int lva_device_synchronize(lva_decoder* d) {
+  if (!d) return LVA_ERR_ARG;
+  HIP_TRY(hipSetDevice(d->device));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  return LVA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,13 @@
+// lva_kernels.h -- launchers of the HIP kernels in lva_kernels.hip (stream passed as void*).
+#pragma once
+#include "lva_device.h"
+
+namespace lva {
+
+int launch_step_exact(const StepArgs& a, const Geometry& g, const DevCode* codes, uint32_t* trellis, void* stream);
+int launch_init_slot(const Geometry& g, const DevCode* codes, uint32_t* trellis, uint32_t slot, uint32_t orient,
+                     void* stream);
+int launch_gather_final(const Geometry& g, const DevCode* codes, const uint32_t* trellis, const GatherArgs& a,
+                        uint32_t* results, void* stream);
+
+}  // namespace lva

@@ -1,0 +1,194 @@
+"""Python face of the C ABI: code description, encoder, batched GPU list decoding.
+
+Mirrors the reference's operator surface for this path:
+  * `encode`  <->  `viterbi_nanopore.out -m encode`  (viterbi_convolutional_code.cpp:215-225)
+  * `Decoder.decode`  <->  `viterbi_nanopore.out -m decode` per read (:226-254), batched.
+"""
+import ctypes
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import LvaError, load_library
+
+_BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def _sm(sync_marker):
+    return sync_marker.encode() if sync_marker else None
+
+
+@dataclass
+class CodeInfo:
+    mem_conv: int
+    rate: int
+    msg_len: int
+    nstate_pos: int
+    nstate_conv: int
+    oligo_len: int
+    msg_words: int
+    initial_state: int
+    final_state: int
+    g: tuple
+    pattern: tuple
+
+
+def code_info(mem_conv, rate, msg_len, rc=False, sync_marker="", sync_period=0):
+    """set_conv_params (:264-415): raises LvaError for parameters the reference rejects."""
+    L = load_library()
+    s = _lib.CodeInfoStruct()
+    st = L.lva_code_describe(mem_conv, rate, msg_len, int(bool(rc)), _sm(sync_marker), sync_period, ctypes.byref(s))
+    if st != 0:
+        raise LvaError(st)
+    return CodeInfo(mem_conv, rate, msg_len, s.nstate_pos, s.nstate_conv, s.oligo_len, s.msg_words,
+                    s.initial_state, s.final_state, (s.g0, s.g1), tuple(s.pattern[:s.pattern_len]))
+
+
+def code_tables(mem_conv, rate, msg_len, rc=False, sync_marker="", sync_period=0):
+    """The per-position / per-conv-state tables the kernels index (for inspection and tests)."""
+    info = code_info(mem_conv, rate, msg_len, rc, sync_marker, sync_period)
+    L = load_library()
+    pos2msg = np.zeros(info.nstate_pos, np.uint32)
+    ptype = np.zeros(info.nstate_pos, np.uint8)
+    vmask = np.zeros(info.nstate_pos, np.uint32)
+    vval = np.zeros(info.nstate_pos, np.uint32)
+    predtab = np.zeros((4, info.nstate_conv), np.uint16)
+    st = L.lva_code_tables(mem_conv, rate, msg_len, int(bool(rc)), _sm(sync_marker), sync_period,
+                           pos2msg.ctypes.data, ptype.ctypes.data, vmask.ctypes.data, vval.ctypes.data,
+                           predtab.ctypes.data)
+    if st != 0:
+        raise LvaError(st)
+    return dict(pos2msg=pos2msg, ptype=ptype, vmask=vmask, vval=vval, predtab=predtab)
+
+
+def encode(mem_conv, rate, msg_len, msgs):
+    """msgs: array [n, msg_len] (or [msg_len]) of 0/1 -> uint8 array [n, oligo_len] of 0..3 (A,C,G,T)."""
+    msgs = np.ascontiguousarray(msgs, dtype=np.uint8)
+    single = msgs.ndim == 1
+    if single:
+        msgs = msgs[None, :]
+    if msgs.shape[1] != msg_len:
+        raise LvaError(-10, "Message length does not match msg_len parameter.")   # :219-222
+    info = code_info(mem_conv, rate, msg_len)
+    out = np.zeros((msgs.shape[0], info.oligo_len), np.uint8)
+    st = load_library().lva_encode(mem_conv, rate, msg_len, msgs.ctypes.data, msgs.shape[0], out.ctypes.data)
+    if st != 0:
+        raise LvaError(st)
+    return out[0] if single else out
+
+
+def bases_to_str(bases):
+    return _BASES[np.asarray(bases, dtype=np.uint8)].tobytes().decode()
+
+
+def str_to_bits(s):
+    return np.frombuffer(s.encode(), dtype=np.uint8) - ord("0")
+
+
+def algorithmic_bytes(mem_conv, rate, msg_len, nblk, list_size, max_deviation=None, rc=False,
+                      sync_marker="", sync_period=0):
+    """sum_t [2 R(t) L (4+4W) + 160] for one read of nblk blocks."""
+    out = ctypes.c_double(0)
+    md = _lib.MAX_DEVIATION_DEFAULT if max_deviation is None else max_deviation
+    st = load_library().lva_algorithmic_bytes(mem_conv, rate, msg_len, int(bool(rc)), _sm(sync_marker), sync_period,
+                                              nblk, list_size, md, ctypes.byref(out))
+    if st != 0:
+        raise LvaError(st)
+    return out.value
+
+
+class Decoder:
+    """A list-Viterbi decoder bound to one GPU.  Fails loudly without a GPU (no CPU path)."""
+
+    def __init__(self, mem_conv, rate, msg_len, list_size=1, max_deviation=None, sync_marker="", sync_period=0,
+                 device=0, max_slots=0, kernel=0, mem_budget_bytes=0):
+        self._L = load_library()
+        self._sync = _sm(sync_marker)
+        cfg = _lib.Config(mem_conv, rate, msg_len, list_size,
+                          _lib.MAX_DEVIATION_DEFAULT if max_deviation is None else max_deviation,
+                          self._sync, sync_period, device, max_slots, kernel, mem_budget_bytes)
+        h = ctypes.c_void_p()
+        st = self._L.lva_decoder_create(ctypes.byref(cfg), ctypes.byref(h))
+        if st != 0:
+            raise LvaError(st, self._L.lva_last_hip_error().decode())
+        self._h = h
+        self.mem_conv, self.rate, self.msg_len, self.list_size = mem_conv, rate, msg_len, list_size
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.lva_decoder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @staticmethod
+    def _pack(posts):
+        posts = [np.ascontiguousarray(p, dtype=np.float32).reshape(-1, 40) for p in posts]
+        off = np.zeros(len(posts) + 1, np.int64)
+        off[1:] = np.cumsum([p.shape[0] for p in posts])
+        flat = np.concatenate(posts, axis=0) if posts else np.zeros((0, 40), np.float32)
+        return np.ascontiguousarray(flat), off
+
+    def _outputs(self, n):
+        return (np.zeros((n, self.list_size, self.msg_len), np.uint8), np.zeros((n, self.list_size), np.float32),
+                np.zeros(n, np.int32))
+
+    def _unpack(self, n, msgs, scores, counts):
+        out = []
+        for i in range(n):
+            c = int(counts[i])
+            out.append((msgs[i, :c].copy(), scores[i, :c].copy()) if c >= 0 else c)
+        return out
+
+    def decode(self, posts, rc=None):
+        """posts: list of float32 [nblk_i, 40] matrices (.post layout).  rc: optional bool per read.
+        -> list of (msgs uint8[count, msg_len], scores float32[count]) or a negative error code per read."""
+        n = len(posts)
+        flat, off = self._pack(posts)
+        rcf = None if rc is None else np.ascontiguousarray(rc, dtype=np.uint8)
+        msgs, scores, counts = self._outputs(n)
+        st = self._L.lva_decode_batch(self._h, flat.ctypes.data, off.ctypes.data, n,
+                                      None if rcf is None else rcf.ctypes.data,
+                                      msgs.ctypes.data, scores.ctypes.data, counts.ctypes.data)
+        if st != 0:
+            raise LvaError(st, self._L.lva_last_hip_error().decode())
+        return self._unpack(n, msgs, scores, counts)
+
+    # --- inputs resident in HBM (bench.py) ---------------------------------------------------
+    def upload(self, posts):
+        flat, off = self._pack(posts)
+        p = ctypes.c_void_p()
+        st = self._L.lva_device_alloc(self._h, flat.nbytes, ctypes.byref(p))
+        if st != 0:
+            raise LvaError(st, self._L.lva_last_hip_error().decode())
+        st = self._L.lva_device_upload(self._h, p, flat.ctypes.data, flat.nbytes)
+        if st != 0:
+            raise LvaError(st, self._L.lva_last_hip_error().decode())
+        return p, off
+
+    def free(self, dev_ptr):
+        self._L.lva_device_free(self._h, dev_ptr)
+
+    def decode_resident(self, dev_ptr, off, rc=None):
+        n = len(off) - 1
+        rcf = None if rc is None else np.ascontiguousarray(rc, dtype=np.uint8)
+        msgs, scores, counts = self._outputs(n)
+        st = self._L.lva_decode_batch_device(self._h, dev_ptr, off.ctypes.data, n,
+                                             None if rcf is None else rcf.ctypes.data,
+                                             msgs.ctypes.data, scores.ctypes.data, counts.ctypes.data)
+        if st != 0:
+            raise LvaError(st, self._L.lva_last_hip_error().decode())
+        return self._unpack(n, msgs, scores, counts)
+
+    def profile(self):
+        p = _lib.Profile()
+        self._L.lva_decoder_profile(self._h, ctypes.byref(p))
+        return {k: getattr(p, k) for k, _ in _lib.Profile._fields_}

@@ -1,0 +1,66 @@
+"""GPU parity: the HIP decoder (through the C ABI) against the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+import nanopore_dna_storage_amd as pkg
+from nanopore_dna_storage_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(oracle, m, r, msg_len, L, md, reads, kernel=0, max_slots=0, sync_marker="", sync_period=0):
+    with pkg.Decoder(m, r, msg_len, list_size=L, max_deviation=md, max_slots=max_slots, kernel=kernel,
+                     sync_marker=sync_marker, sync_period=sync_period) as dec:
+        got = dec.decode([x["post"] for x in reads], rc=[x["rc"] for x in reads])
+    for i, (x, g) in enumerate(zip(reads, got)):
+        code = oracle.OracleCode(m, r, msg_len, rc=x["rc"], sync_marker=sync_marker, sync_period=sync_period)
+        want_msgs, want_scores = code.decode(x["post"], L, md, num_threads=4)
+        assert not isinstance(g, int), "read %d: error %r" % (i, g)
+        assert g[0].shape == want_msgs.shape, "read %d: %d entries, oracle %d" % (i, len(g[0]), len(want_msgs))
+        assert np.array_equal(g[0], want_msgs), "read %d: list differs" % i
+        assert np.array_equal(g[1].view(np.uint32), want_scores.view(np.uint32)), "read %d: scores differ" % i
+
+
+CASES = [
+    # m, rate, msg_len, L, max_dev, n_reads, margin, rc_mode
+    (6, 1, 60, 1, 20, 4, 6.0, "odd"),
+    (6, 1, 60, 4, 20, 4, 3.0, "odd"),
+    (6, 3, 60, 8, 10, 4, 3.0, "odd"),
+    (6, 5, 180, 8, 20, 3, 3.0, "odd"),
+    (8, 1, 100, 8, 20, 2, 3.0, "odd"),
+    (8, 2, 100, 2, 20, 2, 4.0, "odd"),
+    (8, 4, 100, 4, 20, 2, 3.0, "odd"),
+    (8, 5, 100, 8, 20, 2, 3.0, "odd"),
+    (6, 1, 60, 8, None, 2, 3.0, "odd"),      # unbanded (reference default max_deviation)
+    (6, 1, 60, 16, 20, 2, 3.0, "odd"),       # list longer than 8
+]
+
+
+@pytest.mark.parametrize("m,r,msg_len,L,md,n,margin,rc_mode", CASES)
+def test_exact_kernel_matches_oracle(oracle, m, r, msg_len, L, md, n, margin, rc_mode):
+    reads = synth.make_reads(m, r, msg_len, n, seed0=100 * m + r, rc_mode=rc_mode, margin=margin)
+    _compare(oracle, m, r, msg_len, L, md, reads, kernel=1)
+
+
+def test_tie_stress(oracle):
+    reads = synth.make_reads(6, 1, 60, 4, seed0=7, rc_mode="odd", margin=3.0, quantum=0.25)
+    _compare(oracle, 6, 1, 60, 8, 20, reads, kernel=1)
+
+
+def test_more_reads_than_slots(oracle):
+    reads = synth.make_reads(6, 1, 60, 7, seed0=50, rc_mode="odd", margin=4.0)
+    _compare(oracle, 6, 1, 60, 4, 20, reads, kernel=1, max_slots=2)
+
+
+def test_sync_marker(oracle):
+    reads = synth.make_reads(6, 1, 60, 2, seed0=9, margin=4.0)
+    _compare(oracle, 6, 1, 60, 4, 20, reads, kernel=1, sync_marker="110", sync_period=9)
+
+
+def test_short_post_is_reported_per_read(oracle):
+    reads = synth.make_reads(6, 1, 60, 2, seed0=3, margin=6.0)
+    posts = [reads[0]["post"], reads[1]["post"][:30]]
+    with pkg.Decoder(6, 1, 60, list_size=2, max_deviation=20) as dec:
+        got = dec.decode(posts)
+    assert not isinstance(got[0], int)
+    assert got[1] == -6
