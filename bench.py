@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py -- reads decoded/sec on the north-star configuration.
+
+One "step" = one pass of the hot path (lva_decode_batch_device) over one batch of synthetic
+reads of BASELINE.json configs[1]'s shape: mem_conv=11, rate=5 (5/6), list_size=8,
+msg_len=180, max_deviation=20, forward and reverse-complement reads mixed.  The posteriors
+are already resident in HBM when the timed region starts.  With N GPUs each rank decodes its
+own shard of reads (reads are independent: no data-path collective; weak scaling) and the
+decoded lists are gathered on rank 0 after the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      achieved algorithmic GB/s of the trellis-step kernel (SURVEY 8d bytes / HIP-event
+                kernel time, measured live on the decoder's stream) against the 8 TB/s HBM peak
+  cpu_baseline  the unmodified reference binary (oracle/_ref) timed on this host on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+M, RATE, MSG_LEN, LIST, MAXDEV = 11, 5, 180, 8, 20
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads-per-step", type=int, default=0, help="reads per GPU per step (0 = number of slots)")
+    ap.add_argument("--slots", type=int, default=0)
+    ap.add_argument("--kernel", type=int, default=0)
+    ap.add_argument("--mem-conv", type=int, default=M)
+    ap.add_argument("--rate", type=int, default=RATE)
+    ap.add_argument("--msg-len", type=int, default=MSG_LEN)
+    ap.add_argument("--list-size", type=int, default=LIST)
+    ap.add_argument("--max-deviation", type=int, default=MAXDEV)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--check", type=int, default=1, help="reads per rank checked against the CPU oracle (outside the timed region)")
+    return ap.parse_args()
+
+
+def cpu_baseline(a, post):
+    """Reference decoder on this host, bounded sample: one read of the benchmark shape with all
+    (<=16) cores of OpenMP (its own -t flag).  Reported, never the target."""
+    from oracle import oracle as O
+    cores = a.cpu_threads or min(os.cpu_count() or 1, 16)
+    nblk = post.shape[0]
+    if O.have_ref():
+        t0 = time.time()
+        rc, lst = O.ref_decode(a.mem_conv, a.rate, a.msg_len, post, a.list_size, a.max_deviation, num_threads=cores)
+        dt = time.time() - t0
+        kind = "reference"
+        ok = rc == 0
+    else:
+        code = O.OracleCode(a.mem_conv, a.rate, a.msg_len)
+        t0 = time.time()
+        lst, _ = code.decode(post, a.list_size, a.max_deviation, num_threads=cores)
+        dt = time.time() - t0
+        kind = "port"
+        ok = True
+        lst = ["".join(map(str, x)) for x in lst]
+    return dict(value=(1.0 / dt) if ok else None, unit="reads/s", cores=cores, kind=kind,
+                sample="1 read (nblk=%d) of the benchmark shape, -t %d; wall %.1f s" % (nblk, cores, dt)), lst
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import nanopore_dna_storage_amd as pkg
+    from nanopore_dna_storage_amd import synth
+
+    dec = pkg.Decoder(a.mem_conv, a.rate, a.msg_len, list_size=a.list_size, max_deviation=a.max_deviation,
+                      device=local, max_slots=a.slots, kernel=a.kernel)
+    slots = dec.profile()["slots"]
+    per_rank = a.reads_per_step or slots
+    # deterministic synthetic shard of this rank: global read index = rank*per_rank + i
+    reads = [synth.make_read(a.mem_conv, a.rate, a.msg_len, seed=1000 + rank * per_rank + i,
+                             rc=bool((rank * per_rank + i) & 1), margin=6.0 if i % 4 else 3.0)
+             for i in range(per_rank)]
+    rc = [x["rc"] for x in reads]
+    dev_ptr, off = dec.upload([x["post"] for x in reads])      # inputs resident in HBM
+
+    def barrier():
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        out = dec.decode_resident(dev_ptr, off, rc)
+    barrier()
+    kern_ms = alg_bytes = 0.0
+    launches = 0
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = dec.decode_resident(dev_ptr, off, rc)    # returns after the stream is drained
+        p = dec.profile()
+        kern_ms += p["step_kernel_ms"]; alg_bytes += p["algorithmic_bytes"]; launches += p["step_launches"]
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        # gather decoded top-1 lists on rank 0 (the path's only exchange step, ~230 B/read)
+        top = np.stack([o[0][0] if (not isinstance(o, int) and len(o[0])) else np.zeros(a.msg_len, np.uint8) for o in out])
+        tl = torch.from_numpy(top).cuda()
+        gl = [torch.empty_like(tl) for _ in range(world)] if rank == 0 else None
+        dist.gather(tl, gl, dst=0)
+
+    # parity spot check against the CPU oracle, outside the timed region
+    from oracle import oracle as O
+    checked = 0
+    for i in range(min(a.check, per_rank)):
+        if a.mem_conv >= 11 and a.msg_len > 100 and i >= 1:
+            break       # one full-size oracle run takes ~1 min on 8 cores
+        code = O.OracleCode(a.mem_conv, a.rate, a.msg_len, rc=rc[i])
+        wm, ws = code.decode(reads[i]["post"], a.list_size, a.max_deviation, num_threads=min(os.cpu_count() or 1, 16))
+        assert np.array_equal(out[i][0], wm) and np.array_equal(out[i][1], ws), "GPU result differs from the oracle"
+        checked += 1
+
+    if rank == 0:
+        total_reads = per_rank * world * a.steps
+        nblk_mean = float(np.mean([x["post"].shape[0] for x in reads]))
+        res = {
+            "metric": "reads decoded/sec (m=%d, r=%d/%d, L=%d, msg_len=%d)" % (a.mem_conv, a.rate, a.rate + 1, a.list_size, a.msg_len),
+            "value": total_reads / dt, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt / max(a.steps, 1), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1] shape: mem_conv=%d rate=%d list_size=%d msg_len=%d max_deviation=%d, "
+                                   "%d reads per GPU per step (mean nblk %.0f), fwd/rc mixed, posteriors resident in HBM"
+                                   % (a.mem_conv, a.rate, a.list_size, a.msg_len, a.max_deviation, per_rank, nblk_mean),
+                       "reads_per_step_per_gpu": per_rank, "slots": slots, "kernel": dec.profile()["kernel"],
+                       "oracle_checked_reads": checked},
+        }
+        achieved = (alg_bytes / 1e9) / (kern_ms / 1e3) if kern_ms > 0 else 0.0
+        res["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                           "frac": achieved / 8000.0, "traffic": None,
+                           "kernel": "trellis step", "launches": launches,
+                           "avg_launch_ms": kern_ms / max(launches, 1),
+                           "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1)}
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                cb, _ = cpu_baseline(a, reads[0]["post"] if not rc[0] else reads[1 % per_rank]["post"])
+                res["cpu_baseline"] = cb
+            except Exception as e:  # pragma: no cover
+                res["cpu_baseline"] = {"value": None, "unit": "reads/s", "cores": 0, "kind": "reference", "sample": "failed: %r" % (e,)}
+        print(json.dumps(res))
+    dec.free(dev_ptr)
+    dec.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
