@@ -54,6 +54,10 @@ struct lva_decoder {
   uint32_t* d_trellis = nullptr;
   uint32_t* d_results = nullptr;
   size_t results_cap = 0;      // reads
+  WorkHdr* d_work = nullptr;   // header followed by the item array
+  uint32_t work_cap = 1u << 20;
+  int kernel = 1;              // 1 = exact, 2 = fast + exact fix-up
+  uint32_t launch_no = 0;
   lva_profile prof{};
 };
 
@@ -215,7 +219,11 @@ int lva_decoder_create(const lva_config* cfg, lva_decoder** out) {
   d->slots = slots;
   if (hipMalloc(&d->d_trellis, (size_t)slots * slot_bytes) != hipSuccess) return fail(LVA_ERR_NOMEM);
   d->prof.slots = slots;
-  d->prof.kernel = cfg->kernel == 0 ? 1 : cfg->kernel;
+  const bool fast_ok = fast_kernel_available(d->g);
+  if (cfg->kernel == 2 && !fast_ok) return fail(LVA_ERR_UNSUPPORTED);
+  d->kernel = cfg->kernel == 1 ? 1 : (fast_ok ? 2 : 1);
+  d->prof.kernel = d->kernel;
+  if (hipMalloc(&d->d_work, sizeof(WorkHdr) + (size_t)d->work_cap * sizeof(uint32_t)) != hipSuccess) return fail(LVA_ERR_NOMEM);
   *out = d;
   return LVA_OK;
 }
@@ -226,6 +234,7 @@ void lva_decoder_destroy(lva_decoder* d) {
   if (d->stream) hipStreamSynchronize(d->stream);
   if (d->d_trellis) hipFree(d->d_trellis);
   if (d->d_results) hipFree(d->d_results);
+  if (d->d_work) hipFree(d->d_work);
   if (d->d_codes) hipFree(d->d_codes);
   if (d->d_predtab) hipFree(d->d_predtab);
   if (d->ev_total0) hipEventDestroy(d->ev_total0);
@@ -297,6 +306,14 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* off
     d->results_cap = (size_t)n;
   }
   if (!timed_total_started) HIP_TRY(hipEventRecord(d->ev_total0, d->stream));
+  {
+    WorkHdr h0;
+    std::memset(&h0, 0, sizeof h0);
+    h0.cap = d->work_cap;
+    HIP_TRY(hipMemcpyAsync(d->d_work, &h0, sizeof h0, hipMemcpyHostToDevice, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));   // h0 is on the stack
+    d->launch_no = 0;
+  }
 
   struct Slot { int32_t read = -1; uint32_t t = 0, nblk = 0, orient = 0, prev_hi = 1; };
   std::vector<Slot> slot((size_t)std::min<size_t>((size_t)d->slots, std::max<size_t>(order.size(), 1)));
@@ -319,7 +336,7 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* off
     }
     if (active == 0) break;
     StepArgs a;
-    a.nslots = 0; a.L = L; a.W = g.W; a.R = g.R; a.band_max = 0; a.pad = 0;
+    a.nslots = 0; a.band_max = 0; a.step_parity = d->launch_no++ & 1u; a.pad = 0;
     for (size_t s = 0; s < slot.size(); ++s) {
       if (slot[s].read < 0) continue;
       SlotStep& ss = a.s[a.nslots++];
@@ -333,7 +350,9 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* off
     }
     if (first_step) { HIP_TRY(hipEventRecord(d->ev_step0, d->stream)); first_step = false; }
     {
-      const int e = launch_step_exact(a, g, d->d_codes, d->d_trellis, d->stream);
+      const int e = d->kernel == 2
+                        ? launch_step_fast(a, g, d->d_codes, d->d_trellis, d->d_work, reinterpret_cast<uint32_t*>(d->d_work + 1), d->stream)
+                        : launch_step_exact(a, g, d->d_codes, d->d_trellis, d->stream);
       if (e) { g_hip_error = hipGetErrorString((hipError_t)e); return LVA_ERR_HIP; }
     }
     d->prof.step_launches += 1;
@@ -357,8 +376,11 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* off
   if (!first_step) HIP_TRY(hipEventRecord(d->ev_step1, d->stream));
   std::vector<uint32_t> host((size_t)n * rec_words);
   if (n > 0) HIP_TRY(hipMemcpyAsync(host.data(), d->d_results, host.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
+  WorkHdr h1;
+  HIP_TRY(hipMemcpyAsync(&h1, d->d_work, sizeof h1, hipMemcpyDeviceToHost, d->stream));
   HIP_TRY(hipEventRecord(d->ev_total1, d->stream));
   HIP_TRY(hipStreamSynchronize(d->stream));
+  d->prof.fixup_states = h1.total;
   float ms = 0;
   if (!first_step) { HIP_TRY(hipEventElapsedTime(&ms, d->ev_step0, d->ev_step1)); }
   d->prof.step_kernel_ms = ms;

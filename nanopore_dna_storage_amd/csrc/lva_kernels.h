@@ -4,7 +4,12 @@
 
 namespace lva {
 
+// whole step with the exact (reference-order) kernel
 int launch_step_exact(const StepArgs& a, const Geometry& g, const DevCode* codes, uint32_t* trellis, void* stream);
+// whole step with the fast kernel, followed by the exact fix-up pass over its work list
+int launch_step_fast(const StepArgs& a, const Geometry& g, const DevCode* codes, uint32_t* trellis, WorkHdr* hdr,
+                     uint32_t* items, void* stream);
+bool fast_kernel_available(const Geometry& g);
 int launch_init_slot(const Geometry& g, const DevCode* codes, uint32_t* trellis, uint32_t slot, uint32_t orient,
                      void* stream);
 int launch_gather_final(const Geometry& g, const DevCode* codes, const uint32_t* trellis, const GatherArgs& a,

@@ -42,19 +42,49 @@ def test_exact_kernel_matches_oracle(oracle, m, r, msg_len, L, md, n, margin, rc
     _compare(oracle, m, r, msg_len, L, md, reads, kernel=1)
 
 
-def test_tie_stress(oracle):
+@pytest.mark.parametrize("m,r,msg_len,L,md,n,margin,rc_mode", [c for c in CASES if c[3] <= 8])
+def test_fast_kernel_matches_oracle(oracle, m, r, msg_len, L, md, n, margin, rc_mode):
+    reads = synth.make_reads(m, r, msg_len, n, seed0=100 * m + r, rc_mode=rc_mode, margin=margin)
+    _compare(oracle, m, r, msg_len, L, md, reads, kernel=2)
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_tie_stress(oracle, kernel):
+    """posteriors on a 0.25 grid: exact fp32 score ties everywhere, libstdc++ heap order decides"""
     reads = synth.make_reads(6, 1, 60, 4, seed0=7, rc_mode="odd", margin=3.0, quantum=0.25)
-    _compare(oracle, 6, 1, 60, 8, 20, reads, kernel=1)
+    _compare(oracle, 6, 1, 60, 8, 20, reads, kernel=kernel)
 
 
-def test_more_reads_than_slots(oracle):
+def test_fast_kernel_queues_ties_for_the_exact_kernel():
+    reads = synth.make_reads(6, 1, 60, 2, seed0=7, margin=3.0, quantum=0.25)
+    with pkg.Decoder(6, 1, 60, list_size=8, max_deviation=20, kernel=2) as dec:
+        dec.decode([x["post"] for x in reads])
+        assert dec.profile()["fixup_states"] > 0
+        assert dec.profile()["kernel"] == 2
+
+
+def test_minus_inf_posteriors(oracle):
+    """-inf log-posteriors (zero probability transitions) go through the exact path"""
+    reads = synth.make_reads(6, 1, 60, 2, seed0=21, margin=4.0)
+    rng = np.random.default_rng(5)
+    for x in reads:
+        p = x["post"].copy()
+        p[rng.random(p.shape) < 0.02] = -np.inf
+        x["post"] = p
+    for kernel in (1, 2):
+        _compare(oracle, 6, 1, 60, 4, 20, reads, kernel=kernel)
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_more_reads_than_slots(oracle, kernel):
     reads = synth.make_reads(6, 1, 60, 7, seed0=50, rc_mode="odd", margin=4.0)
-    _compare(oracle, 6, 1, 60, 4, 20, reads, kernel=1, max_slots=2)
+    _compare(oracle, 6, 1, 60, 4, 20, reads, kernel=kernel, max_slots=2)
 
 
-def test_sync_marker(oracle):
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_sync_marker(oracle, kernel):
     reads = synth.make_reads(6, 1, 60, 2, seed0=9, margin=4.0)
-    _compare(oracle, 6, 1, 60, 4, 20, reads, kernel=1, sync_marker="110", sync_period=9)
+    _compare(oracle, 6, 1, 60, 4, 20, reads, kernel=kernel, sync_marker="110", sync_period=9)
 
 
 def test_short_post_is_reported_per_read(oracle):
