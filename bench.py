@@ -107,11 +107,14 @@ def main():
     barrier()
     kern_ms = alg_bytes = 0.0
     launches = 0
+    fix = 0
+    fixr = [0, 0, 0, 0]
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = dec.decode_resident(dev_ptr, off, rc)    # returns after the stream is drained
         p = dec.profile()
         kern_ms += p["step_kernel_ms"]; alg_bytes += p["algorithmic_bytes"]; launches += p["step_launches"]
+        fix += p["fixup_states"]; fixr = [x + y for x, y in zip(fixr, p["fixup_reason"])]
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -148,7 +151,7 @@ def main():
                                    "%d reads per GPU per step (mean nblk %.0f), fwd/rc mixed, posteriors resident in HBM"
                                    % (a.mem_conv, a.rate, a.list_size, a.msg_len, a.max_deviation, per_rank, nblk_mean),
                        "reads_per_step_per_gpu": per_rank, "slots": slots, "kernel": dec.profile()["kernel"],
-                       "oracle_checked_reads": checked},
+                       "oracle_checked_reads": checked, "fixup_states": fix, "fixup_reason": fixr},
         }
         achieved = (alg_bytes / 1e9) / (kern_ms / 1e3) if kern_ms > 0 else 0.0
         res["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",

@@ -71,6 +71,8 @@ typedef struct lva_profile {
   uint64_t read_steps;        /* sum over reads of nblk (one launch advances every active read one step) */
   double algorithmic_bytes;   /* sum over reads of sum_t [2 R(t) L (4+4W) + 160] */
   uint64_t fixup_states;      /* states redone by the exact kernel (kernel mode 2) */
+  uint64_t fixup_reason[4];   /* of which: score tie on top, non-finite arithmetic, too many fingerprint
+                                 matches, fingerprint collision */
   int32_t slots;              /* reads in flight */
   int32_t kernel;             /* kernel mode used */
 } lva_profile;

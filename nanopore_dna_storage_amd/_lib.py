@@ -56,6 +56,7 @@ class Profile(ctypes.Structure):
     _fields_ = [("step_kernel_ms", ctypes.c_double), ("total_ms", ctypes.c_double),
                 ("step_launches", ctypes.c_uint64), ("read_steps", ctypes.c_uint64),
                 ("algorithmic_bytes", ctypes.c_double), ("fixup_states", ctypes.c_uint64),
+                ("fixup_reason", ctypes.c_uint64 * 4),
                 ("slots", ctypes.c_int32), ("kernel", ctypes.c_int32)]
 
 

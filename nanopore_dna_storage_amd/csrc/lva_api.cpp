@@ -381,6 +381,7 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* off
   HIP_TRY(hipEventRecord(d->ev_total1, d->stream));
   HIP_TRY(hipStreamSynchronize(d->stream));
   d->prof.fixup_states = h1.total;
+  for (int i = 0; i < 4; ++i) d->prof.fixup_reason[i] = h1.reason[i];
   float ms = 0;
   if (!first_step) { HIP_TRY(hipEventElapsedTime(&ms, d->ev_step0, d->ev_step1)); }
   d->prof.step_kernel_ms = ms;

@@ -70,6 +70,7 @@ struct WorkHdr {
   unsigned long long total;      // states redone since the last reset (profile)
   uint32_t cap;
   uint32_t pad;
+  unsigned long long reason[4];  // why: 0 tie on top, 1 non-finite arithmetic, 2 too many fingerprint matches, 3 fingerprint collision
 };
 
 // final-state gather: result record per read = [crf 8][list L][field F] words

@@ -314,16 +314,29 @@ __global__ __launch_bounds__(256) void lva_step_fixup(StepArgs args, Geometry g,
 // ---------------------------------------------------------------------------------------
 namespace {
 
+// Runtime-indexed read of a small register array as a compare/select chain.  The empty asm
+// makes each element an opaque value: without it LLVM folds select(load a[i], load a[j]) into a
+// load from a selected ADDRESS, which pins the whole array in scratch memory.
 template <int N> __device__ __forceinline__ float pick(const float (&a)[N], uint32_t idx) {
   float r = a[0];
+  asm("" : "+v"(r));
 #pragma unroll
-  for (int i = 1; i < N; ++i) r = idx == (uint32_t)i ? a[i] : r;
+  for (int i = 1; i < N; ++i) {
+    float ai = a[i];
+    asm("" : "+v"(ai));
+    r = idx == (uint32_t)i ? ai : r;
+  }
   return r;
 }
 template <int N> __device__ __forceinline__ uint32_t pick(const uint32_t (&a)[N], uint32_t idx) {
   uint32_t r = a[0];
+  asm("" : "+v"(r));
 #pragma unroll
-  for (int i = 1; i < N; ++i) r = idx == (uint32_t)i ? a[i] : r;
+  for (int i = 1; i < N; ++i) {
+    uint32_t ai = a[i];
+    asm("" : "+v"(ai));
+    r = idx == (uint32_t)i ? ai : r;
+  }
   return r;
 }
 template <int N, typename T> __device__ __forceinline__ void put(T (&a)[N], uint32_t idx, T v) {
@@ -354,13 +367,12 @@ template <int W> __device__ __forceinline__ void push_bits(uint32_t (&m)[W], uin
   }
 }
 
-constexpr int kRejCap = 6;     // fingerprint matches verified per target before giving up
-
 // One target state on the fast path.  NL = 8 (flip target) or 2 (flop target).
 // s_src: LDS image [crf 8][LL][64] of (score, fingerprint) pairs of the source conv states.
-// Returns false when the target must be redone by the exact kernel.
+// Returns 0, or the reason (1 tie, 2 non-finite, 3 too many matches, 4 collision) why the
+// target must be redone by the exact kernel.
 template <int LL, int W, int NL>
-__device__ __forceinline__ bool fast_merge(const Geometry& g, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur,
+__device__ __forceinline__ int fast_merge(const Geometry& g, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur,
                                            const uint2* s_src, const float* s_post, uint32_t k, uint32_t c, uint32_t cp,
                                            uint32_t sc, uint32_t own, uint32_t src, uint32_t okmask, uint32_t sh,
                                            uint32_t nb) {
@@ -406,10 +418,16 @@ __device__ __forceinline__ bool fast_merge(const Geometry& g, const uint32_t* __
   float as[LL]; uint32_t ah[LL]; uint32_t asrc[LL];
 #pragma unroll
   for (int l = 0; l < LL; ++l) { as[l] = NEG; ah[l] = 0; asrc[l] = 0; }
-  uint32_t ptr = 0, lc = 0, nrej = 0;
-  unsigned long long rej = 0;
+  // fingerprint matches waiting for verification, filed under the accepted entry they matched:
+  // two slots of 7 bits (valid, list, index).  A message can sit in at most three lists (stay,
+  // flip X, flop X of the base it ends in), so an accepted entry collects at most two.
+  uint32_t rejs[LL];
+#pragma unroll
+  for (int l = 0; l < LL; ++l) rejs[l] = 0;
+  uint32_t ptr = 0, lc = 0;
 
-  while (good && lc < (uint32_t)LL) {                                  // :764
+  int why = good ? 0 : 2;
+  while (why == 0 && lc < (uint32_t)LL) {                              // :764
     float M = h[0];
 #pragma unroll
     for (int i = 1; i < NL; ++i) M = fmaxf(M, h[i]);
@@ -417,7 +435,7 @@ __device__ __forceinline__ bool fast_merge(const Geometry& g, const uint32_t* __
     uint32_t mask = 0;
 #pragma unroll
     for (int i = 0; i < NL; ++i) mask |= (h[i] == M ? 1u : 0u) << i;
-    if (mask & (mask - 1)) { good = false; break; }   // equal scores on top: heap order decides
+    if (mask & (mask - 1)) { why = 1; break; }        // equal scores on top: heap order decides
     const uint32_t sel = __builtin_ctz(mask);
     const uint32_t j = (ptr >> (4 * sel)) & 15u;
     const uint32_t ch = pick<NL>(hh, sel);
@@ -425,9 +443,10 @@ __device__ __forceinline__ bool fast_merge(const Geometry& g, const uint32_t* __
 #pragma unroll
     for (int a = 0; a < LL; ++a) dup = ((uint32_t)a < lc && ah[a] == ch) ? a : dup;
     if (dup >= 0) {
-      if (nrej == (uint32_t)kRejCap) { good = false; break; }
-      rej |= (unsigned long long)((sel << 7) | (j << 3) | (uint32_t)dup) << (10 * nrej);
-      ++nrej;
+      const uint32_t cur_slots = pick<LL>(rejs, (uint32_t)dup);
+      if (cur_slots & 0x2000u) { why = 3; break; }   // third match on one entry: cannot all be real
+      const uint32_t rec = 0x40u | (sel << 3) | j;
+      put<LL>(rejs, (uint32_t)dup, (cur_slots & 0x40u) ? (cur_slots | (rec << 7)) : rec);
     } else {                                                           // :780-783
       put<LL>(as, lc, M); put<LL>(ah, lc, ch); put<LL>(asrc, lc, (sel << 4) | j);
       ++lc;
@@ -436,20 +455,26 @@ __device__ __forceinline__ bool fast_merge(const Geometry& g, const uint32_t* __
     float ns = NEG; uint32_t nh = 0;
     if (j + 1 < (uint32_t)LL) {
       float raw; float a;
-      if (sel == 0) { raw = pick<LL>(st_s, j + 1); nh = pick<LL>(st_h, j + 1); a = add[0]; }
-      else {
-        const uint2 v = s_src[(list_crf(k, sel) * LL + j + 1) * 64 + sc];
-        raw = u2f(v.x); nh = fp_advance(v.y, sh, nb); a = pick<NL>(add, sel);
+      if (sel == 0) {
+        // the stay list is consumed front to back: slide it so that its next element is [1]
+        // (static register indices only -- a runtime index would send the array to scratch)
+        raw = st_s[1]; nh = st_h[1]; a = add[0];
+#pragma unroll
+        for (int l = 1; l + 1 < LL; ++l) { st_s[l] = st_s[l + 1]; st_h[l] = st_h[l + 1]; }
+      } else {
+        const uint32_t kk = list_crf(k, sel);
+        const uint2 v = s_src[(kk * LL + j + 1) * 64 + sc];
+        raw = u2f(v.x); nh = fp_advance(v.y, sh, nb); a = s_post[row * 8 + kk];
       }
       if (raw != NEG) {
         ns = raw + a;
-        if (!(ns > NEG)) good = false;     // overflowed to -inf: the reference would still queue it
+        if (!(ns > NEG)) why = 2;          // overflowed to -inf: the reference would still queue it
       }
     }
     put<NL>(h, sel, ns); put<NL>(hh, sel, nh);
     ptr += 1u << (4 * sel);
   }
-  if (!good) return false;
+  if (why) return why;
 
   // scores + fingerprints, coalesced per list entry (:781, :799)
 #pragma unroll
@@ -457,7 +482,9 @@ __device__ __forceinline__ bool fast_merge(const Geometry& g, const uint32_t* __
     *reinterpret_cast<uint2*>(cur + own_sh + l * sBlk) =
         (uint32_t)l < lc ? make_uint2(f2u(as[l]), ah[l]) : make_uint2(kNegInfBits, 0u);
 
-  // surviving messages: gather from HBM, shift in the new bits, store coalesced (:771-774, :780)
+  // surviving messages: gather from HBM, shift in the new bits, store coalesced (:771-774, :780);
+  // every fingerprint match filed under the entry must be the same message, else the exact
+  // kernel redoes the target
 #pragma unroll
   for (int l = 0; l < LL; ++l) {
     if ((uint32_t)l < lc) {
@@ -468,23 +495,23 @@ __device__ __forceinline__ bool fast_merge(const Geometry& g, const uint32_t* __
       load_msg<W>(prev + from, m);
       push_bits<W>(m, i == 0 ? 0u : sh, nb);
       store_msg<W>(cur + own_msg + l * sBlk, m);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const uint32_t rec = (rejs[l] >> (7 * s)) & 0x7Fu;
+        if (rec & 0x40u) {
+          const uint32_t ri = (rec >> 3) & 7u, rj = rec & 7u;
+          const uint32_t rfrom = ri == 0 ? own_msg + rj * sBlk
+                                         : src + list_crf(k, ri) * sCrf + rj * sBlk + 2 * N + W * cp;
+          uint32_t q[W];
+          load_msg<W>(prev + rfrom, q);
+          push_bits<W>(q, ri == 0 ? 0u : sh, nb);
+#pragma unroll
+          for (int w = 0; w < W; ++w) good &= (q[w] == m[w]);
+        }
+      }
     }
   }
-  // every fingerprint match must be a real duplicate, else the exact kernel redoes the target
-  for (uint32_t r = 0; r < nrej; ++r) {
-    const uint32_t rec = (uint32_t)(rej >> (10 * r)) & 0x3FFu;
-    const uint32_t i = rec >> 7, j = (rec >> 3) & 15u, a = rec & 7u;
-    const uint32_t from = i == 0 ? own_msg + j * sBlk : src + list_crf(k, i) * sCrf + j * sBlk + 2 * N + W * cp;
-    uint32_t m[W], kept[W];
-    load_msg<W>(prev + from, m);
-    push_bits<W>(m, i == 0 ? 0u : sh, nb);
-    load_msg<W>(cur + own_msg + a * sBlk, kept);
-    bool same = true;
-#pragma unroll
-    for (int w = 0; w < W; ++w) same &= (m[w] == kept[w]);
-    good &= same;
-  }
-  return good;
+  return good ? 0 : 4;
 }
 
 // L == 1: plain add-compare-select, first maximum wins (:715-742).  No heap, no ties issue.
@@ -546,8 +573,13 @@ __global__ __launch_bounds__(256) void lva_step_fast(StepArgs args, Geometry g, 
 
   if (pos == 0) {                          // stay-only update of the 8 start states (:706-713)
     if (tile == cd.init / 64 && tid < 8) {
-      Target tg;
-      if (resolve_target(cd, g, ss, 0, cd.init, tid, &tg)) exact_state(g, ss, prev, cur, tg, 0);
+      const uint32_t k = tid, c = cd.init;
+      const uint32_t own = (uint32_t)((uint64_t)k * g.sCrf), own_sh = own + 2 * c, own_msg = own + 2 * N + W * c;
+      const float s = u2f(prev[own_sh]) + ss.post_row[(k >= 4 ? 4u : k) * 8 + k];
+      cur[own_sh] = f2u(s);
+      cur[own_sh + 1] = prev[own_sh + 1];
+      for (int w = 0; w < W; ++w) cur[own_msg + w] = prev[own_msg + w];
+      for (int l = 1; l < LL; ++l) cur[own_sh + l * g.sBlk] = kNegInfBits;
     }
     return;
   }
@@ -595,18 +627,19 @@ __global__ __launch_bounds__(256) void lva_step_fast(StepArgs args, Geometry g, 
     const uint32_t k = base + 4 * half;
     const uint32_t own = (uint32_t)(((uint64_t)(pos % g.R) * 8 + k) * g.sCrf);
     uint32_t ok = stay_ok;
-    bool done;
+    int why;
     if (half == 0) {
 #pragma unroll
       for (uint32_t i = 1; i < 8; ++i) ok |= ((reach >> list_crf(k, i)) & 1u) << i;
-      if constexpr (LL == 1) { fast_acs<W, 8>(g, prev, cur, s_src, s_post, k, c, cp, sc, own, src, ok, sh, nb); done = true; }
-      else done = fast_merge<LL, W, 8>(g, prev, cur, s_src, s_post, k, c, cp, sc, own, src, ok, sh, nb);
+      if constexpr (LL == 1) { fast_acs<W, 8>(g, prev, cur, s_src, s_post, k, c, cp, sc, own, src, ok, sh, nb); why = 0; }
+      else why = fast_merge<LL, W, 8>(g, prev, cur, s_src, s_post, k, c, cp, sc, own, src, ok, sh, nb);
     } else {
       ok |= ((reach >> base) & 1u) << 1;
-      if constexpr (LL == 1) { fast_acs<W, 2>(g, prev, cur, s_src, s_post, k, c, cp, sc, own, src, ok, sh, nb); done = true; }
-      else done = fast_merge<LL, W, 2>(g, prev, cur, s_src, s_post, k, c, cp, sc, own, src, ok, sh, nb);
+      if constexpr (LL == 1) { fast_acs<W, 2>(g, prev, cur, s_src, s_post, k, c, cp, sc, own, src, ok, sh, nb); why = 0; }
+      else why = fast_merge<LL, W, 2>(g, prev, cur, s_src, s_post, k, c, cp, sc, own, src, ok, sh, nb);
     }
-    if (!done) {
+    if (why) {
+      atomicAdd(&hdr->reason[why - 1], 1ull);
       const uint32_t idx = atomicAdd(&hdr->count[args.step_parity], 1u);
       if (idx < hdr->cap) items[idx] = (blockIdx.z << 25) | (blockIdx.y << 17) | (k << 14) | c;
       else hdr->overflow[args.step_parity] = 1u;

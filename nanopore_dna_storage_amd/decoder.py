@@ -191,4 +191,6 @@ class Decoder:
     def profile(self):
         p = _lib.Profile()
         self._L.lva_decoder_profile(self._h, ctypes.byref(p))
-        return {k: getattr(p, k) for k, _ in _lib.Profile._fields_}
+        d = {k: getattr(p, k) for k, _ in _lib.Profile._fields_}
+        d["fixup_reason"] = list(p.fixup_reason)
+        return d
