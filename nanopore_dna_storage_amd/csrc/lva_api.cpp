@@ -163,6 +163,8 @@ static int upload_codes(lva_decoder* d) {
     std::memcpy(dc[o].ptype, c.ptype, sizeof dc[o].ptype);
     std::memcpy(dc[o].vmask, c.vmask, sizeof dc[o].vmask);
     std::memcpy(dc[o].vval, c.vval, sizeof dc[o].vval);
+    std::memcpy(dc[o].fpc, c.fpc, sizeof dc[o].fpc);
+    for (uint32_t p = 0; p < c.npos; ++p) dc[o].npair[p] = (uint8_t)std::max<uint32_t>(1, (c.nbits[p] + 63) / 64);
     for (int T = 0; T < 4; ++T)
       dc[o].predtab[T] = c.predtab[T].empty() ? nullptr : d->d_predtab + ((size_t)o * 4 + T) * N;
   }
@@ -190,7 +192,7 @@ int lva_decoder_create(const lva_config* cfg, lva_decoder** out) {
   if ((uint64_t)c.npos * kCrf * c.nconv >= ((uint64_t)1 << 32)) { delete d; return LVA_ERR_TOO_MANY_STATES; }
   d->max_dev = cfg->max_deviation == LVA_MAX_DEVIATION_DEFAULT ? c.msg_len + (uint32_t)c.mem_conv + 1 : cfg->max_deviation;
   const uint64_t ring = std::min<uint64_t>(c.npos, 2ull * d->max_dev + 1);
-  d->g = make_geometry(c.nconv, cfg->list_size, c.msg_words(), (uint32_t)std::max<uint64_t>(ring, 1));
+  d->g = make_geometry(c.nconv, cfg->list_size, c.msg_bits(), (uint32_t)std::max<uint64_t>(ring, 1));
   if (d->g.sPar >= ((uint64_t)1 << 32)) { delete d; return LVA_ERR_TOO_MANY_STATES; }
 
   int ndev = 0;

@@ -11,6 +11,15 @@ namespace lva {
 
 namespace {
 
+// fixed pseudo-random word of message bit index i (message fingerprints, lva_device.h)
+uint32_t fp_word(uint32_t i) {
+  uint64_t z = (uint64_t)(i + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 16) | 1u;
+}
+
 uint32_t reverse_bits(uint32_t v, uint32_t n) {           // :417-424
   uint32_t r = 0;
   for (uint32_t i = 0; i < n; ++i) r |= ((v >> i) & 1u) << (n - 1 - i);
@@ -112,6 +121,18 @@ int build_code(Code* c, int mem_conv, int rate, uint32_t msg_len, int rc, const 
       if (want >= 0) { mask |= 1u << bitpos; val |= (uint32_t)want << bitpos; }
     }
     c->vmask[pos] = mask; c->vval[pos] = val;
+  }
+  // bits consumed per position and the fingerprint delta of each step (kernel bookkeeping,
+  // no counterpart in the reference)
+  for (uint32_t pos = 1; pos < c->npos; ++pos) {
+    const uint32_t sh = c->shift_of(c->ptype[pos]), n0 = c->nbits[pos - 1];
+    c->nbits[pos] = n0 + sh;
+    for (uint32_t nb = 0; nb < 4; ++nb) {
+      uint32_t d = 0;
+      if (sh == 1) d = (nb & 1u) ? fp_word(n0) : 0u;
+      else d = ((nb & 2u) ? fp_word(n0) : 0u) ^ ((nb & 1u) ? fp_word(n0 + 1) : 0u);
+      c->fpc[pos][nb] = d;
+    }
   }
 
   // ---- predecessor table (find_prev_states :860-942) -------------------------------------

@@ -38,10 +38,13 @@ struct Code {
   // derived tables
   uint8_t ptype[kMaxPos] = {0};          // block type of the step INTO pos (0 for pos 0)
   uint32_t vmask[kMaxPos] = {0}, vval[kMaxPos] = {0};
+  uint32_t nbits[kMaxPos] = {0};         // message bits consumed on arrival at pos (either orientation)
+  uint32_t fpc[kMaxPos][4] = {{0}};      // fingerprint delta of the step into pos, by new bits (lva_device.h)
   std::vector<uint16_t> predtab[4];      // [type][nconv], empty when the rate never uses the type
   std::vector<uint32_t> reach_per_pos;   // structurally reachable (conv,crf) states per position
 
   uint32_t msg_words() const { return (msg_len + (uint32_t)mem_conv + 31) / 32; }
+  uint32_t msg_bits() const { return msg_len + (uint32_t)mem_conv; }
   uint32_t oligo_len() const { return npos - 1; }
   uint32_t shift_of(int type) const { return type == 0 ? 1u : 2u; }
   bool valid(uint32_t pos, uint32_t c) const { return (c & vmask[pos]) == vval[pos]; }

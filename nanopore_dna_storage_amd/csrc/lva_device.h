@@ -1,14 +1,17 @@
 // lva_device.h -- structures shared by the host driver (lva_api.cpp) and the HIP kernels.
 //
 // Trellis memory (HBM), per read slot:
-//     block[parity 2][ring R][crf 8][list L]   each block = N conv states x F words:
-//         words [0, 2N)        (score fp32 bits, message fingerprint) pairs, conv-major   "SH"
-//         words [2N, 2N + W*N) message-so-far, W little-endian words per conv state       "MSG"
-//   F = 2 + W, W = message words rounded up to even (8-byte aligned per-lane accesses).
+//     block[parity 2][ring R][crf 8][list L]   each block = 1+P planes of N conv states x 8 bytes:
+//         plane 0      (score fp32 bits, message fingerprint) pairs                        "SH"
+//         plane 1..P   the message so far, 64 bits per plane, least significant pair first  "MSG"
+//   P = ceil((msg_len + mem_conv) / 64) pairs; W = 2P words; F = 2 + W words per entry.
 //   * conv fastest: a wavefront of 64 consecutive conv states reads/writes 512 contiguous
-//     bytes of SH and 64*4W contiguous bytes of MSG per list entry -- every store of the step
-//     kernels is fully coalesced, and the list-head/score traffic (SH) is separated from the
-//     message traffic (MSG), which is only touched for entries that survive the merge.
+//     bytes per plane -- every store of the step kernels is fully coalesced, and the list-head
+//     traffic (SH) is separated from the message traffic (MSG), which is only touched for
+//     entries that survive the merge.
+//   * message planes are position dependent: a state at trellis position p has consumed
+//     nbits[p] message bits, so only planes 1..ceil(nbits[p]/64) are ever written or read
+//     there (higher bits are zero by construction).  Halves the message traffic on average.
 //   * ring: only positions [band_lo-1, band_hi) of the two parity buffers are live
 //     (reference :677-679 band; the extra position below the band carries the reference's
 //     stale-score behaviour), so R = min(nstate_pos, 2*max_deviation+1)
@@ -16,6 +19,11 @@
 //   * states the reference leaves at -inf forever (invalid conv states :700, and (conv,crf)
 //     pairs whose only predecessor is "stay") are neither stored nor read: readers test the
 //     same predicates instead.
+//
+// Message fingerprint: XOR over the set message bits of a fixed pseudo-random 32-bit word per
+// bit index (index = order of consumption).  Appending bits at a step XORs a constant that
+// depends only on (position, new bits): fpc[pos][newbits].  Equal messages have equal
+// fingerprints; the converse is verified on the full message wherever it decides anything.
 #pragma once
 #include <cstdint>
 
@@ -26,7 +34,9 @@ constexpr int kMaxSlots = 64;
 struct DevCode {                 // one per orientation (0 = forward, 1 = reverse complement)
   uint32_t m, nconv, npos, init, fin;
   uint8_t ptype[256];            // block type of the step into pos
+  uint8_t npair[256];            // message planes in use at pos: max(1, ceil(nbits[pos]/64))
   uint32_t vmask[256], vval[256];
+  uint32_t fpc[256][4];          // fingerprint delta of the step into pos, by new bits
   const uint16_t* predtab[4];    // device pointers, [nconv] each (nullptr when unused)
 };
 
@@ -48,14 +58,15 @@ struct StepArgs {
 };
 
 struct Geometry {                // strides in 32-bit words
-  uint32_t N, L, W, F, R;
+  uint32_t N, L, W, F, R, P;
   uint32_t sBlk;                 // one (ring, crf, list entry) block = N*F
   uint64_t sCrf, sRing, sPar, sSlot;
 };
 
-inline Geometry make_geometry(uint32_t N, uint32_t L, uint32_t msg_words, uint32_t R) {
+inline Geometry make_geometry(uint32_t N, uint32_t L, uint32_t msg_bits, uint32_t R) {
   Geometry g;
-  g.N = N; g.L = L; g.W = (msg_words + 1u) & ~1u; g.F = g.W + 2; g.R = R;
+  g.N = N; g.L = L; g.P = (msg_bits + 63) / 64; if (g.P == 0) g.P = 1;
+  g.W = 2 * g.P; g.F = g.W + 2; g.R = R;
   g.sBlk = N * g.F;
   g.sCrf = (uint64_t)g.sBlk * L; g.sRing = g.sCrf * 8;
   g.sPar = g.sRing * R; g.sSlot = g.sPar * 2;
