@@ -204,8 +204,8 @@ int lva_decoder_create(const lva_config* cfg, lva_decoder** out) {
   auto fail = [&](int code) { lva_decoder_destroy(d); return code; };
   if (hipSetDevice(d->device) != hipSuccess) return fail(LVA_ERR_NO_DEVICE);
   if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) return fail(LVA_ERR_HIP);
-  hipEventCreate(&d->ev_total0); hipEventCreate(&d->ev_total1);
-  hipEventCreate(&d->ev_step0); hipEventCreate(&d->ev_step1);
+  (void)hipEventCreate(&d->ev_total0); (void)hipEventCreate(&d->ev_total1);
+  (void)hipEventCreate(&d->ev_step0); (void)hipEventCreate(&d->ev_step1);
   {
     const int st = upload_codes(d);
     if (st != LVA_OK) return fail(st);
@@ -232,18 +232,18 @@ int lva_decoder_create(const lva_config* cfg, lva_decoder** out) {
 
 void lva_decoder_destroy(lva_decoder* d) {
   if (!d) return;
-  hipSetDevice(d->device);
-  if (d->stream) hipStreamSynchronize(d->stream);
-  if (d->d_trellis) hipFree(d->d_trellis);
-  if (d->d_results) hipFree(d->d_results);
-  if (d->d_work) hipFree(d->d_work);
-  if (d->d_codes) hipFree(d->d_codes);
-  if (d->d_predtab) hipFree(d->d_predtab);
-  if (d->ev_total0) hipEventDestroy(d->ev_total0);
-  if (d->ev_total1) hipEventDestroy(d->ev_total1);
-  if (d->ev_step0) hipEventDestroy(d->ev_step0);
-  if (d->ev_step1) hipEventDestroy(d->ev_step1);
-  if (d->stream) hipStreamDestroy(d->stream);
+  (void)hipSetDevice(d->device);
+  if (d->stream) (void)hipStreamSynchronize(d->stream);
+  if (d->d_trellis) (void)hipFree(d->d_trellis);
+  if (d->d_results) (void)hipFree(d->d_results);
+  if (d->d_work) (void)hipFree(d->d_work);
+  if (d->d_codes) (void)hipFree(d->d_codes);
+  if (d->d_predtab) (void)hipFree(d->d_predtab);
+  if (d->ev_total0) (void)hipEventDestroy(d->ev_total0);
+  if (d->ev_total1) (void)hipEventDestroy(d->ev_total1);
+  if (d->ev_step0) (void)hipEventDestroy(d->ev_step0);
+  if (d->ev_step1) (void)hipEventDestroy(d->ev_step1);
+  if (d->stream) (void)hipStreamDestroy(d->stream);
   delete d;
 }
 
@@ -302,7 +302,7 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* off
   std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return off[a + 1] - off[a] > off[b + 1] - off[b]; });
 
   if ((size_t)n > d->results_cap) {
-    if (d->d_results) hipFree(d->d_results);
+    if (d->d_results) (void)hipFree(d->d_results);
     d->d_results = nullptr;
     HIP_TRY(hipMalloc(&d->d_results, (size_t)n * rec_words * sizeof(uint32_t)));
     d->results_cap = (size_t)n;
@@ -419,10 +419,10 @@ int lva_decode_batch(lva_decoder* d, const float* post, const int64_t* row_offse
   hipError_t e = hipEventRecord(d->ev_total0, d->stream);
   if (e == hipSuccess && blocks > 0)
     e = hipMemcpyAsync(dev, post, (size_t)blocks * 40 * sizeof(float), hipMemcpyHostToDevice, d->stream);
-  if (e != hipSuccess) { g_hip_error = hipGetErrorString(e); hipFree(dev); return LVA_ERR_HIP; }
+  if (e != hipSuccess) { g_hip_error = hipGetErrorString(e); (void)hipFree(dev); return LVA_ERR_HIP; }
   const int st = decode_impl(d, dev, row_offsets, n_reads, rc_flags, out_msgs, out_scores, out_counts, true);
-  hipStreamSynchronize(d->stream);
-  hipFree(dev);
+  (void)hipStreamSynchronize(d->stream);
+  (void)hipFree(dev);
   return st;
 }
 

@@ -1,0 +1,168 @@
+"""Host-side helpers around the decode path, mirroring the parts of the reference's helper.py
+that sit next to the decoder call (helper.py:305): post truncation (helper.py:211-224), reverse
+complement (:227-229), bit/byte conversions (:365-369) and the CRC-8 / index filter over a
+decoded list (:371-388).  Everything else in the reference's helper.py (signal simulation,
+fast5 writing, barcode search, RS glue) needs scrappy / fast5_research / schifra and is out of
+scope.
+
+CRC-8: the reference calls the PyPI module `crc8` (unpinned, install_python_packages.sh:3), which
+is not installable here.  Its algorithm -- polynomial x^8+x^2+x+1 (0x07), init 0, no reflection,
+no final xor -- is restated below and pinned by the standard check value crc8("123456789") = 0xF4.
+"""
+import math
+
+import numpy as np
+
+# PRP x -> a*x+b mod 2^12 that randomises the oligo index (helper.py:28-32)
+prp_a = 1751
+prp_b = 2532
+prp_a_inv = 3303
+index_len = 12
+crc_len = 8
+
+BYTES_PER_BLOCK = 160      # 40 float32 per flappie block (helper.py:211-216)
+
+_COMPLEMENT = str.maketrans("ACGTN", "TGCAN")
+
+
+def reverse_complement(dna):
+    """helper.py:227-229 (raises KeyError-like ValueError on letters outside ACGTN, as the dict lookup does)."""
+    if any(ch not in "ACGTN" for ch in dna):
+        raise KeyError(next(ch for ch in dna if ch not in "ACGTN"))
+    return dna.translate(_COMPLEMENT)[::-1]
+
+
+def read_seq(path):
+    with open(path) as f:
+        return f.readline().rstrip("\n")
+
+
+def truncate_post(post, start_pos, end_pos):
+    """rows [start_pos, end_pos] (inclusive) of a [nblk, 40] posterior matrix"""
+    post = np.asarray(post, dtype=np.float32).reshape(-1, 40)
+    assert end_pos >= start_pos
+    assert post.shape[0] >= end_pos + 1
+    return post[start_pos:end_pos + 1]
+
+
+def truncate_post_file(old_post_filename, new_post_filename, start_pos, end_pos, bytes_per_blk=BYTES_PER_BLOCK):
+    """helper.py:211-224: byte-slice blocks [start_pos, end_pos] of a .post file into a new file."""
+    with open(old_post_filename, "rb") as f:
+        data = f.read()
+    assert len(data) % bytes_per_blk == 0
+    assert end_pos >= start_pos
+    assert len(data) >= (end_pos + 1) * bytes_per_blk
+    with open(new_post_filename, "wb") as f:
+        f.write(data[start_pos * bytes_per_blk:(end_pos + 1) * bytes_per_blk])
+
+
+def read_post_file(path):
+    """read_crf_post (viterbi_convolutional_code.cpp:553-575) -> float32 [nblk, 40].
+    Like the reference, a trailing partial block is completed with the last value read."""
+    raw = np.fromfile(path, dtype="<f4")
+    full, rem = divmod(raw.size, 40)
+    if rem == 0:
+        return raw.reshape(full, 40)
+    tail = np.full(40, raw[-1], dtype=np.float32)
+    tail[:rem] = raw[full * 40:]
+    return np.concatenate([raw[:full * 40].reshape(full, 40), tail[None, :]], axis=0)
+
+
+def bitstring2bytestring(bitstring, bitstring_len):
+    """helper.py:365-366: value of the bit string, left-padded with zeros to bitstring_len bits."""
+    return int(bitstring, 2).to_bytes(bitstring_len // 8, "big")
+
+
+def bytestring2bitstring(bytestring, bitstring_len):
+    """helper.py:368-369"""
+    return format(int.from_bytes(bytestring, "big"), "b").zfill(bitstring_len)
+
+
+_CRC_TABLE = []
+for _i in range(256):
+    _c = _i
+    for _ in range(8):
+        _c = ((_c << 1) ^ 0x07) & 0xFF if _c & 0x80 else (_c << 1) & 0xFF
+    _CRC_TABLE.append(_c)
+
+
+def crc8(data):
+    """CRC-8 (poly 0x07, init 0x00, unreflected, xorout 0) -> bytes of length 1, like crc8.crc8(...).digest()"""
+    c = 0
+    for b in data:
+        c = _CRC_TABLE[c ^ b]
+    return bytes([c])
+
+
+def compute_parameters(bytes_per_oligo, RS_redundancy, data_size_padded, pad):
+    """helper.py:352-363 (without the prints)"""
+    msg_len = index_len + crc_len + 8 * bytes_per_oligo + int(bool(pad))
+    assert data_size_padded % bytes_per_oligo == 0
+    num_oligos_data = data_size_padded // bytes_per_oligo
+    num_oligos_RS = int(num_oligos_data * RS_redundancy)
+    return msg_len, num_oligos_data, num_oligos_RS, num_oligos_data + num_oligos_RS
+
+
+def attach_index_crc(index, payload, pad=False):
+    """The bit string helper.encode writes per oligo (helper.py:253-262): PRP(index) | payload | CRC-8 [| 0]."""
+    index_prp = (prp_a * index + prp_b) % (2 ** index_len)
+    bits = format(index_prp, "b").zfill(index_len)
+    index_bytes = bitstring2bytestring(bits, 8 * math.ceil(index_len / 8))
+    crc = crc8(index_bytes + payload)
+    out = bits + bytestring2bitstring(payload + crc, 8 * len(payload) + crc_len)
+    return out + "0" if pad else out
+
+
+def decode_list_CRC_index(decoded_msg_list, bytes_per_oligo, num_oligos, pad):
+    """helper.py:371-388: first list entry whose CRC-8 checks and whose de-randomised index is in
+    range -> (index, payload_bytes, entry); (None, None, None) when no entry qualifies."""
+    for entry in decoded_msg_list:
+        msg = entry[:-1] if pad else entry
+        nbits = math.ceil(len(msg) / 8) * 8
+        as_bytes = bitstring2bytestring(msg, nbits)
+        if crc8(as_bytes[:-crc_len // 8]) != as_bytes[-crc_len // 8:]:
+            continue
+        nidx = math.ceil(index_len / 8)
+        idx_bits = bytestring2bitstring(as_bytes[:nidx], 8 * nidx)[-index_len:]
+        index = (prp_a_inv * (int(idx_bits, 2) - prp_b)) % (2 ** index_len)
+        payload = bitstring2bytestring(msg[index_len:-crc_len], bytes_per_oligo * 8)
+        if index < num_oligos:
+            return index, payload, entry
+    return None, None, None
+
+
+def hamming(a, b):
+    """distance.hamming: number of differing positions of two equal-length sequences"""
+    if len(a) != len(b):
+        raise ValueError("expected two strings of the same length")
+    return sum(x != y for x, y in zip(a, b))
+
+
+def levenshtein(a, b):
+    """distance.levenshtein: unit-cost edit distance"""
+    if len(a) < len(b):
+        a, b = b, a
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i]
+        for j, cb in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+        prev = cur
+    return prev[-1]
+
+
+def tally_decoded_lists(lists, conv_input_list, bytes_per_oligo, pad, list_size):
+    """compute_error_rate_from_decoded_lists.py:18-56 over in-memory lists:
+    -> dict(num_reads, num_correct, num_erasure_CRC_index, num_error_CRC_index)"""
+    num_oligos = len(conv_input_list)
+    out = dict(num_reads=0, num_correct=0, num_erasure_CRC_index=0, num_error_CRC_index=0)
+    for lst in lists:
+        out["num_reads"] += 1
+        index, _, msg = decode_list_CRC_index(lst[:list_size], bytes_per_oligo, num_oligos, pad)
+        if index is None:
+            out["num_erasure_CRC_index"] += 1
+        elif msg == conv_input_list[index]:
+            out["num_correct"] += 1
+        else:
+            out["num_error_CRC_index"] += 1
+    return out

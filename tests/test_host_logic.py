@@ -1,0 +1,155 @@
+"""Host-side logic that needs no GPU: helper functions with known answers, the CLI shim's
+encode mode and error behaviour, the C ABI's export list, and the no-fallback rule."""
+import ctypes
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+
+import nanopore_dna_storage_amd as pkg
+from nanopore_dna_storage_amd import _lib, helper, synth, viterbi_nanopore
+from golden_util import encode_cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "lva_decoder.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(lva_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTS)
+    L = ctypes.CDLL(pkg.library_path())
+    for name in declared:
+        assert hasattr(L, name), name
+    assert b"gfx950" in pkg.load_library().lva_version()
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.LvaError) as e:
+        pkg.Decoder(6, 1, 60)
+    assert e.value.code == -11
+
+
+def test_crc8_known_answers():
+    assert helper.crc8(b"123456789") == b"\xf4"        # CRC-8 (poly 0x07) check value
+    assert helper.crc8(b"") == b"\x00"
+    assert helper.crc8(b"\x00\x00") == b"\x00"
+    assert helper.crc8(b"\x01") == b"\x07"
+
+
+def test_bit_byte_conversions():
+    assert helper.bitstring2bytestring("1", 8) == b"\x01"
+    assert helper.bitstring2bytestring("110000000001", 16) == b"\x0c\x01"     # left zero padding (helper.py:378-379)
+    assert helper.bytestring2bitstring(b"\x0c\x01", 16) == "0000110000000001"
+    s = "1011001110001111"
+    assert helper.bytestring2bitstring(helper.bitstring2bytestring(s, 16), 16) == s
+
+
+def test_reverse_complement():
+    assert helper.reverse_complement("AACGTN") == "NACGTT"
+    bases = np.array([0, 0, 1, 2, 3], np.uint8)
+    assert pkg.bases_to_str(synth.reverse_complement_bases(bases)) == helper.reverse_complement(pkg.bases_to_str(bases))
+    with pytest.raises(KeyError):
+        helper.reverse_complement("AXG")
+
+
+def test_truncate_post_file(tmp_path):
+    post = np.arange(10 * 40, dtype=np.float32).reshape(10, 40)
+    a, b = tmp_path / "a.post", tmp_path / "b.post"
+    post.tofile(a)
+    helper.truncate_post_file(str(a), str(b), 2, 5)
+    got = helper.read_post_file(str(b))
+    assert np.array_equal(got, post[2:6])
+    assert os.path.getsize(b) == 4 * 160
+    assert np.array_equal(helper.truncate_post(post, 2, 5), post[2:6])
+    with pytest.raises(AssertionError):
+        helper.truncate_post_file(str(a), str(b), 5, 10)
+
+
+def test_read_post_file_partial_block(tmp_path):
+    """read_crf_post (:553-575) completes a trailing partial block with the last value read"""
+    vals = np.arange(45, dtype=np.float32)
+    f = tmp_path / "p.post"
+    vals.tofile(f)
+    got = helper.read_post_file(str(f))
+    assert got.shape == (2, 40)
+    assert np.array_equal(got[1, :5], vals[40:]) and np.all(got[1, 5:] == vals[-1])
+
+
+def test_crc_index_filter_roundtrip():
+    payload = bytes(range(18))
+    entry = helper.attach_index_crc(37, payload)
+    assert len(entry) == 12 + 8 * 18 + 8
+    bad = "".join("1" if c == "0" else "0" for c in entry[:3]) + entry[3:]
+    idx, pay, msg = helper.decode_list_CRC_index([bad, entry], 18, 100, False)
+    assert (idx, pay, msg) == (37, payload, entry)
+    assert helper.decode_list_CRC_index([bad], 18, 100, False) == (None, None, None)
+    assert helper.decode_list_CRC_index([entry], 18, 30, False) == (None, None, None)     # index out of range
+    padded = helper.attach_index_crc(5, payload, pad=True)
+    assert helper.decode_list_CRC_index([padded], 18, 100, True)[0] == 5
+    t = helper.tally_decoded_lists([[entry], [bad]], {37: entry} and [entry if i == 37 else "" for i in range(100)], 18, False, 8)
+    assert t == dict(num_reads=2, num_correct=1, num_erasure_CRC_index=1, num_error_CRC_index=0)
+
+
+def test_distances():
+    assert helper.hamming("10110", "10011") == 2
+    assert helper.levenshtein("kitten", "sitting") == 3
+    assert helper.levenshtein("", "abc") == 3
+    with pytest.raises(ValueError):
+        helper.hamming("1", "11")
+
+
+def test_compute_parameters():
+    assert helper.compute_parameters(18, 0.3, 180, False) == (164, 10, 3, 13)
+    assert helper.compute_parameters(20, 0.0, 40, True)[0] == 12 + 8 + 160 + 1
+
+
+def test_cli_encode_matches_reference(tmp_path):
+    c = [x for x in encode_cases()["cases"] if (x["mem_conv"], x["rate"]) == (11, 5)][0]
+    fin, fout = tmp_path / "in.txt", tmp_path / "out.txt"
+    fin.write_text("".join(m + "\n" for m in c["msgs"]))
+    rc = viterbi_nanopore.main(["-m", "encode", "-i", str(fin), "-o", str(fout), "--mem-conv", "11", "-r", "5",
+                                "--msg-len", str(c["msg_len"]), ""], out=io.StringIO())
+    assert rc == 0
+    assert fout.read_text().split() == c["oligos"]
+
+
+def test_cli_error_behaviour(tmp_path):
+    fin = tmp_path / "in.txt"
+    fin.write_text("0101\n")
+    out = io.StringIO()
+    base = ["-i", str(fin), "-o", str(tmp_path / "o")]
+    assert viterbi_nanopore.main(["-m", "encode"] + base + ["--msg-len", "4"], out=out) == 255
+    assert "Memory of convolutional code not specified." in out.getvalue()
+    out = io.StringIO()
+    assert viterbi_nanopore.main(["-m", "encode"] + base + ["--mem-conv", "7", "--msg-len", "4"], out=out) == 255
+    assert "Invalid mem_conv" in out.getvalue()
+    out = io.StringIO()
+    assert viterbi_nanopore.main(["-m", "encode"] + base + ["--mem-conv", "6", "-r", "3", "--msg-len", "5"], out=out) == 255
+    assert "Output length not even" in out.getvalue()
+    out = io.StringIO()
+    assert viterbi_nanopore.main(["-m", "transcode"] + base + ["--mem-conv", "6", "--msg-len", "4"], out=out) == 255
+    assert "Invalid mode." in out.getvalue()
+    out = io.StringIO()
+    assert viterbi_nanopore.main(["-m", "encode"] + base + ["--mem-conv", "6", "--msg-len", "6"], out=out) == 255
+    assert "Message length does not match" in out.getvalue()
+    assert viterbi_nanopore.main(["-h"], out=io.StringIO()) == 0
+    assert not os.path.exists(tmp_path / "o")
+
+
+def test_synthetic_generator_is_deterministic_and_normalised():
+    a = synth.make_read(6, 1, 60, seed=5, rc=True, margin=4.0)
+    b = synth.make_read(6, 1, 60, seed=5, rc=True, margin=4.0)
+    assert np.array_equal(a["post"], b["post"]) and np.array_equal(a["msg"], b["msg"])
+    assert a["post"].dtype == np.float32 and a["post"].shape[1] == 40
+    lse = np.log(np.exp(a["post"].astype(np.float64)).sum(axis=1))
+    assert np.allclose(lse, 0, atol=1e-5)
+    assert a["post"].shape[0] >= len(a["read_bases"]) + 1
+    st = synth.state_path([0, 0, 0, 1, 1, 2])
+    assert list(st) == [0, 4, 0, 1, 5, 2]
+    assert synth.transition_index(3, 1) == 1 * 8 + 3 and synth.transition_index(2, 6) == 34 and synth.transition_index(6, 6) == 38
