@@ -456,12 +456,12 @@ __global__ __launch_bounds__(256) void lva_step_fixup(StepArgs args, Geometry g,
 // ---------------------------------------------------------------------------------------
 namespace {
 
-// Runtime-indexed write of a small register array as a compare/select chain (static register
-// indices only: a runtime index would send the array to scratch memory).
-template <int N, typename T> __device__ __forceinline__ void put(T (&a)[N], uint32_t idx, T v) {
-#pragma unroll
-  for (int i = 0; i < N; ++i) a[i] = idx == (uint32_t)i ? v : a[i];
-}
+// An opaque copy of a register value.  Selecting between two elements of a local array,
+// `c ? a[i] : a[j]`, is folded by LLVM into a load from a selected ADDRESS, which pins the whole
+// array in scratch memory; routing the operands through an empty asm keeps them register values.
+template <typename T> __device__ __forceinline__ T opq(T x) { asm("" : "+v"(x)); return x; }
+// c ? a : b on register values (both operands made opaque BEFORE the select: no control flow)
+template <typename T> __device__ __forceinline__ T selv(bool c, T a, T b) { a = opq(a); b = opq(b); return c ? a : b; }
 
 // message of an entry: P planes of 64 bits; planes >= np are zero and are not read
 template <int P> __device__ __forceinline__ void load_msg(const uint32_t* __restrict__ blk, uint32_t plane_words, uint32_t np,
@@ -536,68 +536,80 @@ __device__ __forceinline__ int fast_merge(const Geometry& g, const uint32_t* __r
     if (ok && !(h[i] > NEG)) why = 2;
   }
 
-  uint32_t ah[LL];                 // fingerprints of the accepted entries
+  // Accepted entries.  ah: their fingerprints, NEWEST FIRST (a shift register: static register
+  // indices only).  asrc: 8 bits (list << 3 | index) per entry in acceptance order.  rej0/rej1:
+  // fingerprint matches waiting for verification, filed under the accepted entry they matched,
+  // 7 bits (valid, list, index) per entry and slot.  A message can sit in at most three lists
+  // (stay, flip X, flop X of the base it ends in), so two slots per entry do.
+  uint32_t ah[LL];
 #pragma unroll
   for (int l = 0; l < LL; ++l) ah[l] = 0;
-  // accepted sources: 8 bits (list << 3 | index) per entry; fingerprint matches waiting for
-  // verification: two 7-bit slots (valid, list, index) per accepted entry.  A message can sit
-  // in at most three lists (stay, flip X, flop X of the base it ends in), so two slots do.
-  uint32_t asrc[2] = {0, 0}, rej0[2] = {0, 0}, rej1[2] = {0, 0};
+  unsigned long long asrc = 0, rej0 = 0, rej1 = 0;
   uint32_t ptr = 0, lc = 0;
 
-  while (why == 0 && lc < (uint32_t)LL) {                              // :764
+  // The loop body is written branch-free (selects) except for the store of an accepted entry:
+  // lanes that are done keep running harmless iterations until the wavefront's last lane exits.
+  bool go = why == 0;
+  while (go) {                                                         // :764
     float M = h[0];
 #pragma unroll
     for (int i = 1; i < NL; ++i) M = fmaxf(M, h[i]);
-    if (!(M > NEG)) break;                 // every list exhausted (heap empty)
-    uint32_t first = NL, last = 0;
+    bool eq[NL];
 #pragma unroll
-    for (int i = NL - 1; i >= 0; --i) first = h[i] == M ? (uint32_t)i : first;
+    for (int i = 0; i < NL; ++i) eq[i] = h[i] == M;
+    // first and last head equal to the maximum; they differ when equal scores sit on top, and
+    // then libstdc++'s heap order decides
+    uint32_t sel = NL - 1, last = 0;
 #pragma unroll
-    for (int i = 0; i < NL; ++i) last = h[i] == M ? (uint32_t)i : last;
-    if (first != last) { why = 1; break; }             // equal scores on top: heap order decides
-    const uint32_t sel = first;
+    for (int i = NL - 2; i >= 0; --i) sel = eq[i] ? (uint32_t)i : sel;
+#pragma unroll
+    for (int i = 1; i < NL; ++i) last = eq[i] ? (uint32_t)i : last;
+    const bool two = sel != last;
+    const bool alive = M > NEG;            // false: every list exhausted (heap empty)
+    const bool proceed = alive && !two;
     const uint32_t j = (ptr >> (4 * sel)) & 15u;
-    // fingerprint of the candidate, and the element that follows it in its list (:788-796)
-    uint32_t ch; float ns = NEG;
-    if (sel == 0) {
-      ch = st_h[0];
-      if (LL > 1) ns = st_s[1];
-      // the stay list is consumed front to back: slide it (static register indices only)
+    // source side, computed for every lane (a stay pop reads list 1's slot harmlessly)
+    const uint32_t kk = list_crf(k, sel == 0 ? 1u : sel);
+    const uint32_t at = (mul24(kk, LL) + j) * 64 + sc;
+    const bool has_next = j + 1 < (uint32_t)LL;
+    const uint32_t fp_src = s_src[at].y ^ fpc;
+    const float raw1 = u2f(s_src[has_next ? at + 64 : at].x);
+    const bool nxt_ok = has_next && raw1 != NEG;
+    const float ns_src = nxt_ok ? raw1 + s_post[row * 8 + kk] : NEG;   // :788-796
+    const bool is_stay = sel == 0;
+    const bool bad = !is_stay && nxt_ok && !(ns_src > NEG);   // overflowed to -inf: the reference would still queue it
+    const uint32_t ch = selv(is_stay, st_h[0], fp_src);
+    const float ns = selv(is_stay, LL > 1 ? st_s[LL > 1 ? 1 : 0] : NEG, ns_src);
+    // the stay list is consumed front to back: slide it when it was popped
 #pragma unroll
-      for (int l = 0; l + 1 < LL; ++l) { st_s[l] = st_s[l + 1]; st_h[l] = st_h[l + 1]; }
-      st_s[LL - 1] = NEG;
-    } else {
-      const uint32_t kk = list_crf(k, sel);
-      const uint32_t at = (mul24(kk, LL) + j) * 64 + sc;
-      ch = s_src[at].y ^ fpc;
-      if (j + 1 < (uint32_t)LL) {
-        const float raw = u2f(s_src[at + 64].x);
-        if (raw != NEG) {
-          ns = raw + s_post[row * 8 + kk];
-          if (!(ns > NEG)) why = 2;        // overflowed to -inf: the reference would still queue it
-        }
-      }
+    for (int l = 0; l + 1 < LL; ++l) {
+      st_s[l] = selv(is_stay, st_s[l + 1], st_s[l]);
+      st_h[l] = selv(is_stay, st_h[l + 1], st_h[l]);
     }
-    int dup = -1;                                                      // :778-779 on fingerprints
+    st_s[LL - 1] = selv(is_stay, NEG, st_s[LL - 1]);
+    // de-duplicate on fingerprints (:778-779): position q in ah <-> accepted entry lc-1-q
+    int q = -1;
 #pragma unroll
-    for (int a = LL - 1; a >= 0; --a) dup = ah[a] == ch ? a : dup;
-    if (dup >= 0 && (uint32_t)dup < lc) {
-      const uint32_t w = (uint32_t)dup >> 2, s7 = 7 * ((uint32_t)dup & 3u);
-      const uint32_t rec = 0x40u | (sel << 3) | j;
-      const uint32_t r0 = w ? rej0[1] : rej0[0], r1 = w ? rej1[1] : rej1[0];
-      if ((r1 >> s7) & 0x40u) { why = 3; break; }      // third match on one entry: cannot all be real
-      if ((r0 >> s7) & 0x40u) { if (w) rej1[1] |= rec << s7; else rej1[0] |= rec << s7; }
-      else { if (w) rej0[1] |= rec << s7; else rej0[0] |= rec << s7; }
-    } else {                                                           // :780-783
-      *reinterpret_cast<uint2*>(cur + own_c + mul24(lc, sBlk)) = make_uint2(f2u(M), ch);
-      put<LL>(ah, lc, ch);
-      const uint32_t v8 = ((sel << 3) | j) << (8 * (lc & 3u));
-      if (lc >> 2) asrc[1] |= v8; else asrc[0] |= v8;
-      ++lc;
-    }
-    put<NL>(h, sel, ns);
+    for (int a = LL - 1; a >= 0; --a) q = ah[a] == ch ? a : q;
+    const bool isdup = q >= 0 && (uint32_t)q < lc;
+    const bool accept = proceed && !isdup, reject = proceed && isdup;
+    const uint32_t s7 = 7u * (lc - 1u - (uint32_t)q);          // (only meaningful when reject)
+    const unsigned long long rec = (unsigned long long)(0x40u | (sel << 3) | j);
+    const bool full0 = reject && ((rej0 >> (s7 & 63u)) & 0x40u), full1 = reject && ((rej1 >> (s7 & 63u)) & 0x40u);
+    rej0 |= (reject && !full0) ? rec << (s7 & 63u) : 0ull;
+    rej1 |= (full0 && !full1) ? rec << (s7 & 63u) : 0ull;
+    if (accept) *reinterpret_cast<uint2*>(cur + own_c + mul24(lc, sBlk)) = make_uint2(f2u(M), ch);   // :780-783
+#pragma unroll
+    for (int a = LL - 1; a >= 1; --a) ah[a] = selv(accept, ah[a - 1], ah[a]);
+    ah[0] = selv(accept, ch, ah[0]);
+    asrc |= accept ? (unsigned long long)((sel << 3) | j) << (8 * lc) : 0ull;
+    lc += accept ? 1u : 0u;
+    // advance the popped list
+#pragma unroll
+    for (int i = 0; i < NL; ++i) h[i] = selv(eq[i], ns, h[i]);
     ptr += 1u << (4 * sel);
+    why = (alive && two) ? 1 : ((proceed && bad) ? 2 : ((full0 && full1) ? 3 : 0));
+    go = proceed && why == 0 && lc < (uint32_t)LL;
   }
   if (why) return why;
 
@@ -613,24 +625,27 @@ __device__ __forceinline__ int fast_merge(const Geometry& g, const uint32_t* __r
 #pragma unroll
   for (int l = 0; l < LL; ++l) {
     if ((uint32_t)l < lc) {
-      const uint32_t a8 = (asrc[l >> 2] >> (8 * (l & 3))) & 0xFFu;
+      const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu;
       const uint32_t i = a8 >> 3, j = a8 & 7u;
       const uint32_t from = i == 0 ? own_c + mul24(j, sBlk) : src_c + mul24(list_crf(k, i), sCrf) + mul24(j, sBlk);
       uint32_t m[2 * P];
       load_msg<P>(prev + from, pw, i == 0 ? np_dst : np_src, m);
       push_bits<2 * P>(m, i == 0 ? 0u : sh, nb);
       store_msg<P>(cur + own_c + l * sBlk, pw, np_dst, m);
+      const uint32_t r0 = (uint32_t)(rej0 >> (7 * l)) & 0x7Fu;
+      if (r0) {
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const uint32_t rec = ((s ? rej1[l >> 2] : rej0[l >> 2]) >> (7 * (l & 3))) & 0x7Fu;
-        if (rec & 0x40u) {
-          const uint32_t ri = (rec >> 3) & 7u, rj = rec & 7u;
-          const uint32_t rfrom = ri == 0 ? own_c + mul24(rj, sBlk) : src_c + mul24(list_crf(k, ri), sCrf) + mul24(rj, sBlk);
-          uint32_t q[2 * P];
-          load_msg<P>(prev + rfrom, pw, ri == 0 ? np_dst : np_src, q);
-          push_bits<2 * P>(q, ri == 0 ? 0u : sh, nb);
+        for (int s = 0; s < 2; ++s) {
+          const uint32_t rec = s ? (uint32_t)(rej1 >> (7 * l)) & 0x7Fu : r0;
+          if (rec & 0x40u) {
+            const uint32_t ri = (rec >> 3) & 7u, rj = rec & 7u;
+            const uint32_t rfrom = ri == 0 ? own_c + mul24(rj, sBlk) : src_c + mul24(list_crf(k, ri), sCrf) + mul24(rj, sBlk);
+            uint32_t qm[2 * P];
+            load_msg<P>(prev + rfrom, pw, ri == 0 ? np_dst : np_src, qm);
+            push_bits<2 * P>(qm, ri == 0 ? 0u : sh, nb);
 #pragma unroll
-          for (int w = 0; w < 2 * P; ++w) good &= (q[w] == m[w]);
+            for (int w = 0; w < 2 * P; ++w) good &= (qm[w] == m[w]);
+          }
         }
       }
     }
