@@ -64,7 +64,8 @@ _lib = None
 
 
 def library_path():
-    return os.path.join(_HERE, _LIB_NAME)
+    # LVA_LIB_PATH: point at another build of the same library (kernel experiments)
+    return os.environ.get("LVA_LIB_PATH") or os.path.join(_HERE, _LIB_NAME)
 
 
 def load_library():
