@@ -76,17 +76,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    backend = os.environ.get("LVA_BENCH_BACKEND", "nccl")    # "gloo": several ranks on one GPU (testing only)
+    ndev = 1
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        ndev = max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local % ndev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local % ndev))
+        else:
+            dist.init_process_group(backend)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
 
     import nanopore_dna_storage_amd as pkg
     from nanopore_dna_storage_amd import synth
 
     dec = pkg.Decoder(a.mem_conv, a.rate, a.msg_len, list_size=a.list_size, max_deviation=a.max_deviation,
-                      device=local, max_slots=a.slots, kernel=a.kernel)
+                      device=local % ndev, max_slots=a.slots, kernel=a.kernel)
     slots = dec.profile()["slots"]
     per_rank = a.reads_per_step or slots
     # deterministic synthetic shard of this rank: global read index = rank*per_rank + i
@@ -119,12 +126,12 @@ def main():
     dt = time.perf_counter() - t0
     if dist is not None:
         import torch
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
         # gather decoded top-1 lists on rank 0 (the path's only exchange step, ~230 B/read)
         top = np.stack([o[0][0] if (not isinstance(o, int) and len(o[0])) else np.zeros(a.msg_len, np.uint8) for o in out])
-        tl = torch.from_numpy(top).cuda()
+        tl = torch.from_numpy(top).to(coll_dev)
         gl = [torch.empty_like(tl) for _ in range(world)] if rank == 0 else None
         dist.gather(tl, gl, dst=0)
 
