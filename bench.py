@@ -116,11 +116,13 @@ def main():
     launches = 0
     fix = 0
     fixr = [0, 0, 0, 0]
+    sum_read_steps = 0
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = dec.decode_resident(dev_ptr, off, rc)    # returns after the stream is drained
         p = dec.profile()
         kern_ms += p["step_kernel_ms"]; alg_bytes += p["algorithmic_bytes"]; launches += p["step_launches"]
+        sum_read_steps += p["read_steps"]
         fix += p["fixup_states"]; fixr = [x + y for x, y in zip(fixr, p["fixup_reason"])]
     barrier()
     dt = time.perf_counter() - t0
@@ -161,8 +163,18 @@ def main():
                        "oracle_checked_reads": checked, "fixup_states": fix, "fixup_reason": fixr},
         }
         achieved = (alg_bytes / 1e9) / (kern_ms / 1e3) if kern_ms > 0 else 0.0
+        # HBM bytes per launch from the committed PMC profile (per read-step, scaled to this run's
+        # mean number of active slots per launch); only for the configuration that was profiled
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+            if (a.mem_conv, a.rate, a.list_size, a.msg_len, a.max_deviation) == (11, 5, 8, 180, 20) and launches:
+                per_step = (tj["fetch_correction"] * tj["fetch_size_kb_per_launch"] + tj["write_size_kb_per_launch"]) * 1024.0 / tj["slots"]
+                traffic = per_step * (sum_read_steps / launches)
+        except Exception:
+            traffic = None
         res["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                           "frac": achieved / 8000.0, "traffic": None,
+                           "frac": achieved / 8000.0, "traffic": traffic,
                            "kernel": "trellis step", "launches": launches,
                            "avg_launch_ms": kern_ms / max(launches, 1),
                            "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1)}
