@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -225,6 +226,10 @@ int lva_decoder_create(const lva_config* cfg, lva_decoder** out) {
   if (cfg->kernel == 2 && !fast_ok) return fail(LVA_ERR_UNSUPPORTED);
   d->kernel = cfg->kernel == 1 ? 1 : (fast_ok ? 2 : 1);
   d->prof.kernel = d->kernel;
+  if (const char* cap = std::getenv("LVA_WORK_CAP")) {       // tests: force the work-list overflow path
+    const long v = std::atol(cap);
+    if (v >= 1 && v <= (1l << 24)) d->work_cap = (uint32_t)v;
+  }
   if (hipMalloc(&d->d_work, sizeof(WorkHdr) + (size_t)d->work_cap * sizeof(uint32_t)) != hipSuccess) return fail(LVA_ERR_NOMEM);
   *out = d;
   return LVA_OK;

@@ -94,3 +94,24 @@ def test_short_post_is_reported_per_read(oracle):
         got = dec.decode(posts)
     assert not isinstance(got[0], int)
     assert got[1] == -6
+
+
+def test_work_list_overflow_falls_back_to_the_exact_step(oracle, monkeypatch):
+    """a 4-entry work list overflows at once on tie-heavy input: the fix-up kernel then redoes whole steps"""
+    monkeypatch.setenv("LVA_WORK_CAP", "4")
+    reads = synth.make_reads(6, 1, 60, 3, seed0=31, rc_mode="odd", margin=3.0, quantum=0.25)
+    _compare(oracle, 6, 1, 60, 8, 20, reads, kernel=2)
+
+
+@pytest.mark.parametrize("md", [0, 1, 2])
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_tiny_bands(oracle, md, kernel):
+    """max_deviation 0 (empty band: the reference writes an empty list), 1 and 2 (ring of 3 / 5 positions)"""
+    reads = synth.make_reads(6, 1, 24, 3, seed0=77, rc_mode="odd", margin=5.0)
+    _compare(oracle, 6, 1, 24, 4, md, reads, kernel=kernel)
+
+
+@pytest.mark.parametrize("m,r,msg_len,L,rc,sync", [(11, 1, 40, 8, False, ""), (11, 2, 61, 4, True, ""), (11, 5, 100, 8, True, "1011")])
+def test_m11_variants(oracle, m, r, msg_len, L, rc, sync):
+    reads = [synth.make_read(m, r, msg_len, 400 + i, rc=rc, margin=3.5) for i in range(2)]
+    _compare(oracle, m, r, msg_len, L, 20, reads, kernel=0, sync_marker=sync, sync_period=12 if sync else 0)
