@@ -124,11 +124,23 @@ __device__ __forceinline__ void slot_buffers(const SlotStep& ss, const Geometry&
 // ---- entry addressing: block base -> plane q of conv state c (2 words) ----
 __device__ __forceinline__ uint32_t plane_off(const Geometry& g, uint32_t q, uint32_t c) { return 2 * g.N * q + 2 * c; }
 
+// Message storage of one entry = the 2N*P words after its SH plane.  How the words of conv
+// state c are laid out depends on np, the number of 64-bit planes in use at the entry's trellis
+// position (uniform over a workgroup), so that a thread moves its message with the widest loads:
+//   np == 1          words 0-1 at [2c]                                  (one 8-byte access)
+//   np >= 2          words 0-3 at [4c]                                  (one 16-byte access)
+//   np == 3          words 4-5 at [4N + 2c]                             (+ one 8-byte access)
+//   np == 4          words 4-7 at [4N + 4c]                             (+ one 16-byte access)
+__device__ __forceinline__ uint32_t msg_word_off(uint32_t N, uint32_t c, uint32_t w, uint32_t np) {
+  if (np == 1) return 2 * c + w;
+  if (w < 4) return 4 * c + w;
+  return 4 * N + (np == 3 ? 2 * c : 4 * c) + (w - 4);
+}
 // read message word w (0 = least significant) of an entry whose block base is `blk`; words in
 // planes that are not in use at the entry's position are zero
 __device__ __forceinline__ uint32_t msg_word(const Geometry& g, const uint32_t* __restrict__ buf, uint32_t blk, uint32_t c,
                                              uint32_t w, uint32_t np) {
-  return (w >> 1) < np ? buf[blk + plane_off(g, 1 + (w >> 1), c) + (w & 1u)] : 0u;
+  return (w >> 1) < np ? buf[blk + 2 * g.N + msg_word_off(g.N, c, w, np)] : 0u;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -148,7 +160,7 @@ __device__ __noinline__ void exact_state(const Geometry& g, const SlotStep& ss, 
   auto list_add = [&](uint32_t i) -> float { return post[tg.row * 8 + (i == 0 ? tg.k : list_crf(tg.k, i))]; };
   auto own_sh = [&](uint32_t l) -> uint32_t { return tg.own + l * sBlk + 2 * tg.c; };
   auto own_word = [&](uint32_t l, uint32_t w) -> uint32_t {
-    return tg.own + l * sBlk + plane_off(g, 1 + (w >> 1), tg.c) + (w & 1u);
+    return tg.own + l * sBlk + 2 * g.N + msg_word_off(g.N, tg.c, w, tg.np_dst);
   };
   // candidate message of entry (i, j): (msg << shift) | newbits, over Wd words
   auto build = [&](uint32_t i, uint32_t j, uint32_t* out) {
@@ -444,7 +456,7 @@ __global__ __launch_bounds__(256) void lva_step_fixup(StepArgs args, Geometry g,
           const uint32_t lowpart = w == 0 ? tg.newbits : (msg_word(g, prev, b, cv, w - 1, np) >> (32 - tg.shift));
           v = (v << tg.shift) | lowpart;
         }
-        cur[tg.own + e * sBlk + plane_off(g, 1 + (w >> 1), tg.c) + (w & 1u)] = v;
+        cur[tg.own + e * sBlk + 2 * g.N + msg_word_off(g.N, tg.c, w, tg.np_dst)] = v;
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -463,24 +475,54 @@ template <typename T> __device__ __forceinline__ T opq(T x) { asm("" : "+v"(x));
 // c ? a : b on register values (both operands made opaque BEFORE the select: no control flow)
 template <typename T> __device__ __forceinline__ T selv(bool c, T a, T b) { a = opq(a); b = opq(b); return c ? a : b; }
 
-// message of an entry: P planes of 64 bits; planes >= np are zero and are not read
-template <int P> __device__ __forceinline__ void load_msg(const uint32_t* __restrict__ blk, uint32_t plane_words, uint32_t np,
+// message of an entry (layout: msg_word_off above).  `ent` = the entry's block base + 2N (start of
+// its message region); words in planes >= np are zero and are not read
+template <int P> __device__ __forceinline__ void load_msg(const uint32_t* __restrict__ ent, uint32_t N, uint32_t c, uint32_t np,
                                                           uint32_t (&m)[2 * P]) {
 #pragma unroll
-  for (int p = 0; p < P; ++p) {
-    uint2 v = make_uint2(0u, 0u);
-    if ((uint32_t)p < np) v = *reinterpret_cast<const uint2*>(blk + plane_words * (1 + p));
-    m[2 * p] = v.x; m[2 * p + 1] = v.y;
+  for (int w = 0; w < 2 * P; ++w) m[w] = 0;
+  if (np == 1) {
+    const uint2 v = *reinterpret_cast<const uint2*>(ent + 2 * c);
+    m[0] = v.x; m[1] = v.y;
+    return;
+  }
+  if constexpr (P >= 2) {
+    const uint4 v = *reinterpret_cast<const uint4*>(ent + 4 * c);
+    m[0] = v.x; m[1] = v.y; m[2] = v.z; m[3] = v.w;
+    if constexpr (P >= 3) {
+      if (np == 3) {
+        const uint2 u = *reinterpret_cast<const uint2*>(ent + 4 * N + 2 * c);
+        m[4] = u.x; m[5] = u.y;
+      }
+    }
+    if constexpr (P >= 4) {
+      if (np == 4) {
+        const uint4 u = *reinterpret_cast<const uint4*>(ent + 4 * N + 4 * c);
+        m[4] = u.x; m[5] = u.y; m[6] = u.z; m[7] = u.w;
+      }
+    }
   }
 }
-template <int P> __device__ __forceinline__ void store_msg(uint32_t* __restrict__ blk, uint32_t plane_words, uint32_t np,
+// non-temporal stores: written once, next read by another CU a step later (+4 % measured)
+template <int P> __device__ __forceinline__ void store_msg(uint32_t* __restrict__ ent, uint32_t N, uint32_t c, uint32_t np,
                                                            const uint32_t (&m)[2 * P]) {
+  if (np == 1) {
+    __builtin_nontemporal_store(m[0], ent + 2 * c); __builtin_nontemporal_store(m[1], ent + 2 * c + 1);
+    return;
+  }
+  if constexpr (P >= 2) {
 #pragma unroll
-  for (int p = 0; p < P; ++p)
-    if ((uint32_t)p < np) {   // non-temporal: written once, next read by another CU a step later (+4 % measured)
-      __builtin_nontemporal_store(m[2 * p], blk + plane_words * (1 + p));
-      __builtin_nontemporal_store(m[2 * p + 1], blk + plane_words * (1 + p) + 1);
+    for (int w = 0; w < 4; ++w) __builtin_nontemporal_store(m[w], ent + 4 * c + w);
+    if constexpr (P >= 3) {
+      if (np == 3) { __builtin_nontemporal_store(m[4], ent + 4 * N + 2 * c); __builtin_nontemporal_store(m[5], ent + 4 * N + 2 * c + 1); }
     }
+    if constexpr (P >= 4) {
+      if (np == 4) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) __builtin_nontemporal_store(m[4 + w], ent + 4 * N + 4 * c + w);
+      }
+    }
+  }
 }
 // m = (m << sh) | nb, sh in {0,1,2}
 template <int W> __device__ __forceinline__ void push_bits(uint32_t (&m)[W], uint32_t sh, uint32_t nb) {
@@ -504,10 +546,9 @@ __device__ __forceinline__ int fast_merge(const Geometry& g, const uint32_t* __r
                                            uint32_t sc, uint32_t own, uint32_t src, uint32_t okmask, uint32_t sh,
                                            uint32_t nb, uint32_t fpc, uint32_t np_dst, uint32_t np_src) {
   const float NEG = -INFINITY;
-  const uint32_t sBlk = g.sBlk, sCrf = mul24(sBlk, LL), pw = 2 * g.N;
+  const uint32_t N = g.N, sBlk = g.sBlk, sCrf = mul24(sBlk, LL), pw = 2 * g.N;   // pw: the SH plane that precedes an entry's message
   const uint32_t row = k >= 4 ? 4u : k;
-  const uint32_t own_c = own + 2 * c;                    // + l*sBlk: SH of own entry l; + pw*(1+p): its planes
-  const uint32_t src_c = src + 2 * cp;
+  const uint32_t own_c = own + 2 * c;                    // + l*sBlk: SH of own entry l
   int why = 0;
 
   // the target's own ("stay") list lives in registers, transition score already added
@@ -630,11 +671,11 @@ __device__ __forceinline__ int fast_merge(const Geometry& g, const uint32_t* __r
     if ((uint32_t)l < lc) {
       const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu;
       const uint32_t i = a8 >> 3, j = a8 & 7u;
-      const uint32_t from = i == 0 ? own_c + mul24(j, sBlk) : src_c + mul24(list_crf(k, i), sCrf) + mul24(j, sBlk);
+      const uint32_t from = i == 0 ? own + mul24(j, sBlk) : src + mul24(list_crf(k, i), sCrf) + mul24(j, sBlk);
       uint32_t m[2 * P];
-      load_msg<P>(prev + from, pw, i == 0 ? np_dst : np_src, m);
+      load_msg<P>(prev + from + pw, N, i == 0 ? c : cp, i == 0 ? np_dst : np_src, m);
       push_bits<2 * P>(m, i == 0 ? 0u : sh, nb);
-      store_msg<P>(cur + own_c + l * sBlk, pw, np_dst, m);
+      store_msg<P>(cur + own + l * sBlk + pw, N, c, np_dst, m);
       const uint32_t r0 = (uint32_t)(rej0 >> (7 * l)) & 0x7Fu;
       if (r0) {
 #pragma unroll
@@ -642,9 +683,9 @@ __device__ __forceinline__ int fast_merge(const Geometry& g, const uint32_t* __r
           const uint32_t rec = s ? (uint32_t)(rej1 >> (7 * l)) & 0x7Fu : r0;
           if (rec & 0x40u) {
             const uint32_t ri = (rec >> 3) & 7u, rj = rec & 7u;
-            const uint32_t rfrom = ri == 0 ? own_c + mul24(rj, sBlk) : src_c + mul24(list_crf(k, ri), sCrf) + mul24(rj, sBlk);
+            const uint32_t rfrom = ri == 0 ? own + mul24(rj, sBlk) : src + mul24(list_crf(k, ri), sCrf) + mul24(rj, sBlk);
             uint32_t qm[2 * P];
-            load_msg<P>(prev + rfrom, pw, ri == 0 ? np_dst : np_src, qm);
+            load_msg<P>(prev + rfrom + pw, N, ri == 0 ? c : cp, ri == 0 ? np_dst : np_src, qm);
             push_bits<2 * P>(qm, ri == 0 ? 0u : sh, nb);
 #pragma unroll
             for (int w = 0; w < 2 * P; ++w) good &= (qm[w] == m[w]);
@@ -665,7 +706,7 @@ __device__ __forceinline__ void fast_acs(const Geometry& g, const uint32_t* __re
   const float NEG = -INFINITY;
   const uint32_t sCrf = g.sBlk, pw = 2 * g.N;
   const uint32_t row = k >= 4 ? 4u : k;
-  const uint32_t own_c = own + 2 * c, src_c = src + 2 * cp;
+  const uint32_t own_c = own + 2 * c;
   float best = NEG; uint32_t bi = 0, bh = 0;
   if (okmask & 1u) {
     const uint2 v = *reinterpret_cast<const uint2*>(prev + own_c);
@@ -682,11 +723,11 @@ __device__ __forceinline__ void fast_acs(const Geometry& g, const uint32_t* __re
   }
   *reinterpret_cast<uint2*>(cur + own_c) = make_uint2(f2u(best), bh);
   if (best != NEG) {
-    const uint32_t from = bi == 0 ? own_c : src_c + mul24(list_crf(k, bi), sCrf);
+    const uint32_t from = bi == 0 ? own : src + mul24(list_crf(k, bi), sCrf);
     uint32_t m[2 * P];
-    load_msg<P>(prev + from, pw, bi == 0 ? np_dst : np_src, m);
+    load_msg<P>(prev + from + pw, g.N, bi == 0 ? c : cp, bi == 0 ? np_dst : np_src, m);
     push_bits<2 * P>(m, bi == 0 ? 0u : sh, nb);
-    store_msg<P>(cur + own_c, pw, np_dst, m);
+    store_msg<P>(cur + own + pw, g.N, c, np_dst, m);
   }
 }
 
@@ -817,8 +858,8 @@ __global__ void lva_gather_final(Geometry g, const DevCode* __restrict__ codes, 
     const uint32_t f = i % g.F, l = (i / g.F) % g.L, k = i / (g.F * g.L);
     uint32_t v = f == 0 ? kNegInfBits : 0u;
     if (((reach >> k) & 1u) && (f < 2 || ((f - 2) >> 1) < np)) {
-      const uint64_t blk = (((uint64_t)(pos % g.R) * 8 + k) * g.L + l) * g.sBlk;
-      v = buf[blk + plane_off(g, f >> 1, c) + (f & 1u)];
+      const uint32_t blk = (uint32_t)((((uint64_t)(pos % g.R) * 8 + k) * g.L + l) * g.sBlk);
+      v = f < 2 ? buf[blk + 2 * c + f] : msg_word(g, buf, blk, c, f - 2, np);
     }
     out[i] = v;
   }
