@@ -468,6 +468,8 @@ __global__ __launch_bounds__(256) void lva_step_fixup(StepArgs args, Geometry g,
 // ---------------------------------------------------------------------------------------
 namespace {
 
+constexpr uint32_t TS = 64;      // source conv states per workgroup tile (workgroup = 8*TS threads); 32 measured 10 % slower
+
 // An opaque copy of a register value.  Selecting between two elements of a local array,
 // `c ? a[i] : a[j]`, is folded by LLVM into a load from a selected ADDRESS, which pins the whole
 // array in scratch memory; routing the operands through an empty asm keeps them register values.
@@ -574,7 +576,7 @@ __device__ __forceinline__ int fast_merge(const Geometry& g, const uint32_t* __r
 #pragma unroll
   for (int i = 1; i < NL; ++i) {
     const uint32_t kk = list_crf(k, i);
-    const uint2 v = s_src[(kk * LL) * 64 + sc];
+    const uint2 v = s_src[(kk * LL) * TS + sc];
     const bool ok = ((okmask >> i) & 1u) && u2f(v.x) != NEG;
     h[i] = ok ? u2f(v.x) + s_post[row * 8 + kk] : NEG;
     if (ok && !(h[i] > NEG)) why = 2;
@@ -614,10 +616,10 @@ __device__ __forceinline__ int fast_merge(const Geometry& g, const uint32_t* __r
     const uint32_t j = (ptr >> (4 * sel)) & 15u;
     // source side, computed for every lane (a stay pop reads list 1's slot harmlessly)
     const uint32_t kk = list_crf(k, sel == 0 ? 1u : sel);
-    const uint32_t at = (mul24(kk, LL) + j) * 64 + sc;
+    const uint32_t at = (mul24(kk, LL) + j) * TS + sc;
     const bool has_next = j + 1 < (uint32_t)LL;
     const uint32_t fp_src = s_src[at].y ^ fpc;
-    const float raw1 = u2f(s_src[has_next ? at + 64 : at].x);
+    const float raw1 = u2f(s_src[has_next ? at + TS : at].x);
     const bool nxt_ok = has_next && raw1 != NEG;
     const float ns_src = nxt_ok ? raw1 + s_post[row * 8 + kk] : NEG;   // :788-796
     const bool is_stay = sel == 0;
@@ -716,7 +718,7 @@ __device__ __forceinline__ void fast_acs(const Geometry& g, const uint32_t* __re
 #pragma unroll
   for (int i = 1; i < NL; ++i) {
     if ((okmask >> i) & 1u) {
-      const uint2 v = s_src[list_crf(k, i) * 64 + sc];
+      const uint2 v = s_src[list_crf(k, i) * TS + sc];
       const float s = u2f(v.x) + s_post[row * 8 + list_crf(k, i)];
       if (s > best) { best = s; bi = i; bh = v.y ^ fpc; }
     }
@@ -737,10 +739,10 @@ __device__ __forceinline__ void fast_acs(const Geometry& g, const uint32_t* __re
 // block = 512 threads: thread (role, base r, target conv) -- role 0 (wavefronts 0-3) merges
 // the flip target of its (conv, base), role 1 (wavefronts 4-7) the flop target.
 template <int LL, int P>
-__global__ __launch_bounds__(512) void lva_step_fast(StepArgs args, Geometry g, const DevCode* __restrict__ codes,
+__global__ __launch_bounds__(8 * TS) void lva_step_fast(StepArgs args, Geometry g, const DevCode* __restrict__ codes,
                                                      uint32_t* __restrict__ trellis, WorkHdr* __restrict__ hdr,
                                                      uint32_t* __restrict__ items) {
-  __shared__ uint2 s_src[8 * LL * 64];
+  __shared__ uint2 s_src[8 * LL * TS];
   __shared__ float s_post[40];
   const SlotStep& ss = args.s[blockIdx.z];
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
@@ -755,7 +757,7 @@ __global__ __launch_bounds__(512) void lva_step_fast(StepArgs args, Geometry g, 
   slot_buffers(ss, g, trellis, &prev, &cur);
 
   if (pos == 0) {                          // stay-only update of the 8 start states (:706-713)
-    if (tile == cd.init / 64 && tid < 8) {
+    if (tile == cd.init / TS && tid < 8) {
       const uint32_t k = tid, c = cd.init;
       const uint32_t own_c = (uint32_t)((uint64_t)k * g.sCrf) + 2 * c;
       const float s = u2f(prev[own_c]) + ss.post_row[(k >= 4 ? 4u : k) * 8 + k];
@@ -770,19 +772,19 @@ __global__ __launch_bounds__(512) void lva_step_fast(StepArgs args, Geometry g, 
 
   // ---- stage the (score, fingerprint) pairs of 64 source conv states: 8 crf x LL rows of 512 B ----
   const uint32_t src = (uint32_t)((uint64_t)((pos - 1) % g.R) * 8 * g.sCrf);
-  for (uint32_t chunk = tid; chunk < 8u * LL * 32u; chunk += 512u) {
-    const uint32_t rowi = chunk >> 5, lane32 = chunk & 31u;       // rowi = crf * LL + l
-    const uint4 v = *reinterpret_cast<const uint4*>(prev + src + (uint64_t)rowi * g.sBlk + 2 * (tile * 64) + 4 * lane32);
-    *reinterpret_cast<uint4*>(&s_src[rowi * 64 + 2 * lane32]) = v;
+  for (uint32_t chunk = tid; chunk < 8u * LL * (TS / 2); chunk += 8u * TS) {
+    const uint32_t rowi = chunk / (TS / 2), lane2 = chunk % (TS / 2);       // rowi = crf * LL + l
+    const uint4 v = *reinterpret_cast<const uint4*>(prev + src + (uint64_t)rowi * g.sBlk + 2 * (tile * TS) + 4 * lane2);
+    *reinterpret_cast<uint4*>(&s_src[rowi * TS + 2 * lane2]) = v;
   }
   if (tid < 40) s_post[tid] = ss.post_row[tid];
   __syncthreads();
 
   // ---- this thread's (role, target conv, base) ----
   const uint32_t T = cd.ptype[pos], sh = T == 0 ? 1u : 2u;
-  const uint32_t Tn = 64u >> sh;                         // target conv states per butterfly leg
-  const uint32_t role = tid >> 8, r = (tid >> 6) & 3u, tcl = tid & 63u;
-  const uint32_t c = tile * Tn + (tcl & (Tn - 1)) + (tcl >> (6 - sh)) * (N >> sh);
+  const uint32_t Tn = TS >> sh;                          // target conv states per butterfly leg
+  const uint32_t role = tid / (4 * TS), r = (tid / TS) & 3u, tcl = tid % TS;
+  const uint32_t c = tile * Tn + (tcl & (Tn - 1)) + (tcl / Tn) * (N >> sh);
   if ((c & cd.vmask[pos]) != cd.vval[pos]) return;       // :700
   const uint32_t pk = cd.predtab[T][c];
   uint32_t base = r;
@@ -796,7 +798,7 @@ __global__ __launch_bounds__(512) void lva_step_fast(StepArgs args, Geometry g, 
   const uint32_t nib = (pk >> (4 * base)) & 0xFu;
   if (!(nib & 8u)) return;
   const uint32_t cp = ((c << sh) | (nib & 7u)) & (N - 1);
-  const uint32_t sc = cp - tile * 64;
+  const uint32_t sc = cp - tile * TS;
   const uint32_t newest = c >> (cd.m - 1), second = (c >> (cd.m - 2)) & 1u;
   const uint32_t nb = sh == 1 ? newest : (2 * second + newest);
   const uint32_t fpc = cd.fpc[pos][nb];
@@ -883,7 +885,7 @@ bool fast_kernel_available(const Geometry& g) {
 template <int LL>
 static int launch_fast_p(const StepArgs& a, const Geometry& g, const DevCode* codes, uint32_t* trellis, WorkHdr* hdr,
                          uint32_t* items, hipStream_t st) {
-  dim3 grid(g.N / 64, a.band_max, a.nslots), block(512);
+  dim3 grid(g.N / TS, a.band_max, a.nslots), block(8 * TS);
   switch (g.P) {
     case 1: hipLaunchKernelGGL((lva_step_fast<LL, 1>), grid, block, 0, st, a, g, codes, trellis, hdr, items); break;
     case 2: hipLaunchKernelGGL((lva_step_fast<LL, 2>), grid, block, 0, st, a, g, codes, trellis, hdr, items); break;
