@@ -10,8 +10,11 @@
 //     traffic (SH) is separated from the message traffic (MSG), which is only touched for
 //     entries that survive the merge.
 //   * message planes are position dependent: a state at trellis position p has consumed
-//     nbits[p] message bits, so only planes 1..ceil(nbits[p]/64) are ever written or read
-//     there (higher bits are zero by construction).  Halves the message traffic on average.
+//     nbits[p] message bits, so only np = ceil(nbits[p]/64) planes' worth of words are ever
+//     written or read there (higher bits are zero by construction): -33 % message bytes.  Inside
+//     an entry's message region the words of one conv state are laid out for the widest
+//     per-lane access the position allows (lva_kernels.hip msg_word_off): 8 bytes when np = 1,
+//     16 bytes (words 0-3 adjacent) when np >= 2, plus 8 or 16 bytes for words 4-7.
 //   * ring: only positions [band_lo-1, band_hi) of the two parity buffers are live
 //     (reference :677-679 band; the extra position below the band carries the reference's
 //     stale-score behaviour), so R = min(nstate_pos, 2*max_deviation+1)
