@@ -224,7 +224,9 @@ int lva_decoder_create(const lva_config* cfg, lva_decoder** out) {
   d->prof.slots = slots;
   const bool fast_ok = fast_kernel_available(d->g);
   if (cfg->kernel == 2 && !fast_ok) return fail(LVA_ERR_UNSUPPORTED);
-  d->kernel = cfg->kernel == 1 ? 1 : (fast_ok ? 2 : 1);
+  // 1 = exact (one thread per target), 2 = fast + fix-up, 3 = wavefront per target (lists of 9..64 entries)
+  if (cfg->kernel == 3 && !wave_kernel_available(d->g)) return fail(LVA_ERR_UNSUPPORTED);
+  d->kernel = cfg->kernel == 1 ? 1 : cfg->kernel == 3 ? 3 : (fast_ok ? 2 : (wave_kernel_available(d->g) ? 3 : 1));
   d->prof.kernel = d->kernel;
   if (const char* cap = std::getenv("LVA_WORK_CAP")) {       // tests: force the work-list overflow path
     const long v = std::atol(cap);
@@ -359,7 +361,8 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* off
     {
       const int e = d->kernel == 2
                         ? launch_step_fast(a, g, d->d_codes, d->d_trellis, d->d_work, reinterpret_cast<uint32_t*>(d->d_work + 1), d->stream)
-                        : launch_step_exact(a, g, d->d_codes, d->d_trellis, d->stream);
+                        : d->kernel == 3 ? launch_step_wave(a, g, d->d_codes, d->d_trellis, d->stream)
+                                         : launch_step_exact(a, g, d->d_codes, d->d_trellis, d->stream);
       if (e) { g_hip_error = hipGetErrorString((hipError_t)e); return LVA_ERR_HIP; }
     }
     d->prof.step_launches += 1;

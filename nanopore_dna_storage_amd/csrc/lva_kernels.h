@@ -10,6 +10,9 @@ int launch_step_exact(const StepArgs& a, const Geometry& g, const DevCode* codes
 int launch_step_fast(const StepArgs& a, const Geometry& g, const DevCode* codes, uint32_t* trellis, WorkHdr* hdr,
                      uint32_t* items, void* stream);
 bool fast_kernel_available(const Geometry& g);
+// whole step with the wavefront-per-target literal merge (2 <= L <= 64)
+int launch_step_wave(const StepArgs& a, const Geometry& g, const DevCode* codes, uint32_t* trellis, void* stream);
+bool wave_kernel_available(const Geometry& g);
 int launch_init_slot(const Geometry& g, const DevCode* codes, uint32_t* trellis, uint32_t slot, uint32_t orient,
                      void* stream);
 int launch_gather_final(const Geometry& g, const DevCode* codes, const uint32_t* trellis, const GatherArgs& a,

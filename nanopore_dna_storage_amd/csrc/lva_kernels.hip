@@ -22,6 +22,8 @@
 //   lva_step_fixup   exact path behind the fast kernel: one wavefront per queued target, the
 //                    candidate heads staged in LDS, the reference's heap merge (:743-800)
 //                    replayed literally, outputs written cooperatively.
+//   lva_step_wave    the literal merge with one wavefront per target over the whole step: list
+//                    sizes 2..64 that have no fast kernel (kernel mode 3).
 //   lva_step_exact   one thread per target state, the same literal merge straight from HBM --
 //                    any list size; kernel mode 1 and the overflow path of the fix-up.
 //   lva_init_slot    initial scores (:657-663)
@@ -450,6 +452,152 @@ __global__ __launch_bounds__(256) void lva_step_fixup(StepArgs args, Geometry g,
 }
 
 // ---------------------------------------------------------------------------------------
+// wave kernel: the literal reference merge with ONE WAVEFRONT PER TARGET, for list sizes
+// 2 <= L <= 64 that have no fast kernel (L = 16, 32, 64, odd sizes).  Lane j holds entry j of
+// each of the target's <= 8 candidate lists (8 registers), heap element e lives in lane e,
+// accepted entry a in lane a; the merge itself is wavefront-uniform (v_readlane), the
+// de-duplication scan over the accepted fingerprints is ONE ballot instead of a loop over L
+// entries, and all loads/stores of list entries are spread over the lanes.
+// grid: x = groups of 4 conv states, y = band position index * 8 + crf state, z = slot.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lva_step_wave(StepArgs args, Geometry g, const DevCode* __restrict__ codes,
+                                                     uint32_t* __restrict__ trellis) {
+  const SlotStep& ss = args.s[blockIdx.z];
+  const uint32_t pos = ss.lo + (blockIdx.y >> 3), k = blockIdx.y & 7u;
+  if (pos >= ss.hi) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const DevCode& cd = codes[ss.orient];
+  if (c >= cd.nconv) return;
+  const uint32_t* prev; uint32_t* cur;
+  slot_buffers(ss, g, trellis, &prev, &cur);
+  Target tg;
+  if (!resolve_target(cd, g, ss, pos, c, k, &tg)) return;              // (uniform per wavefront)
+  const uint32_t L = g.L, sBlk = g.sBlk, sCrf = (uint32_t)g.sCrf;
+  const uint32_t Wd = 2 * tg.np_dst;
+  const float NEG = -INFINITY;
+  const uint32_t own_sh = tg.own + 2 * tg.c;
+  if (pos == 0) {                                                      // :706-713
+    if (lane == 0) {
+      cur[own_sh] = f2u(u2f(prev[own_sh]) + ss.post_row[tg.row * 8 + k]);
+      cur[own_sh + 1] = prev[own_sh + 1];
+    }
+    if (lane < Wd) cur[tg.own + 2 * g.N + msg_word_off(g.N, tg.c, lane, tg.np_dst)] = prev[tg.own + 2 * g.N + msg_word_off(g.N, tg.c, lane, tg.np_dst)];
+    if (lane >= 1 && lane < L) cur[own_sh + lane * sBlk] = kNegInfBits;
+    return;
+  }
+  auto rdf = [](float v, uint32_t ln) -> float { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)ln)); };
+  auto rdu = [](uint32_t v, uint32_t ln) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)ln); };
+  auto wrf = [lane](float& v, uint32_t ln, float x) { v = lane == ln ? x : v; };
+  auto wru = [lane](uint32_t& v, uint32_t ln, uint32_t x) { v = lane == ln ? x : v; };
+  // 1. candidates: register i of lane j = entry j of list i (score, fingerprint with the step's delta applied)
+  float cs[8]; uint32_t cy[8];
+#pragma unroll
+  for (uint32_t i = 0; i < 8; ++i) {
+    cs[i] = NEG; cy[i] = 0;
+    if (i < tg.nlists && ((tg.okmask >> i) & 1u) && lane < L) {
+      const uint32_t b = (i == 0 ? tg.own : tg.src + list_crf(k, i) * sCrf) + lane * sBlk + 2 * (i == 0 ? tg.c : tg.cp);
+      const uint2 v = *reinterpret_cast<const uint2*>(prev + b);
+      cs[i] = u2f(v.x); cy[i] = i != 0 ? v.y ^ tg.fpc : v.y;
+    }
+  }
+  auto cand_s = [&](uint32_t i, uint32_t j) -> float {      // i, j wavefront-uniform
+    float v = cs[0];
+#pragma unroll
+    for (uint32_t u = 1; u < 8; ++u) v = i == u ? cs[u] : v;
+    return rdf(v, j);
+  };
+  auto cand_y = [&](uint32_t i, uint32_t j) -> uint32_t {
+    uint32_t v = cy[0];
+#pragma unroll
+    for (uint32_t u = 1; u < 8; ++u) v = i == u ? cy[u] : v;
+    return rdu(v, j);
+  };
+  float addv = 0.0f;                                        // transition score of list i in lane i
+  if (lane < tg.nlists) addv = ss.post_row[tg.row * 8 + (lane == 0 ? k : list_crf(k, lane))];
+  // word w of the candidate message built from entry (li, lj): per-lane arguments allowed
+  auto word_of = [&](uint32_t li, uint32_t lj, uint32_t w) -> uint32_t {
+    const uint32_t b = (li == 0 ? tg.own : tg.src + list_crf(k, li) * sCrf) + lj * sBlk;
+    const uint32_t cv = li == 0 ? tg.c : tg.cp, np = li == 0 ? tg.np_dst : tg.np_src;
+    const uint32_t v = msg_word(g, prev, b, cv, w, np);
+    if (li == 0) return v;
+    const uint32_t lowpart = w == 0 ? tg.newbits : (msg_word(g, prev, b, cv, w - 1, np) >> (32 - tg.shift));
+    return (v << tg.shift) | lowpart;
+  };
+  // 2. the reference merge (:743-800): GCC 11 bits/stl_heap.h restated on lane-resident arrays
+  float hs = NEG; uint32_t hx = 0;                          // heap element e in lane e
+  float as = NEG; uint32_t ay = 0, ax = 0;                  // accepted entry a in lane a
+  auto sift_up = [&](uint32_t hole, uint32_t top, float vs, uint32_t vx) {
+    while (hole > top) {
+      const uint32_t parent = (hole - 1) / 2;
+      const float ps = rdf(hs, parent);
+      if (!(ps < vs)) break;
+      wrf(hs, hole, ps); wru(hx, hole, rdu(hx, parent));
+      hole = parent;
+    }
+    wrf(hs, hole, vs); wru(hx, hole, vx);
+  };
+  auto adjust = [&](uint32_t hole, uint32_t len, float vs, uint32_t vx) {
+    const uint32_t top = hole;
+    uint32_t child = hole;
+    while (child < (len - 1) / 2) {
+      child = 2 * (child + 1);
+      if (rdf(hs, child) < rdf(hs, child - 1)) --child;
+      wrf(hs, hole, rdf(hs, child)); wru(hx, hole, rdu(hx, child));
+      hole = child;
+    }
+    if ((len & 1u) == 0 && child == (len - 2) / 2) {
+      child = 2 * (child + 1);
+      wrf(hs, hole, rdf(hs, child - 1)); wru(hx, hole, rdu(hx, child - 1));
+      hole = child - 1;
+    }
+    sift_up(hole, top, vs, vx);
+  };
+  uint32_t hn = 0;
+  for (uint32_t i = 0; i < tg.nlists; ++i) {                           // :750-761
+    const float head = cand_s(i, 0);
+    if (head != NEG) { wrf(hs, hn, head + rdf(addv, i)); wru(hx, hn, i << 16); ++hn; }
+  }
+  if (hn >= 2)                                                         // std::make_heap :762
+    for (uint32_t parent = (hn - 2) / 2;; --parent) {
+      adjust(parent, hn, rdf(hs, parent), rdu(hx, parent));
+      if (parent == 0) break;
+    }
+  uint32_t l = 0;
+  while (hn > 0 && l < L) {                                            // :764
+    const float ts = rdf(hs, 0); const uint32_t tx = rdu(hx, 0);       // pop_heap + back + pop_back :766-768
+    if (hn > 1) adjust(0, hn - 1, rdf(hs, hn - 1), rdu(hx, hn - 1));
+    --hn;
+    const uint32_t i = tx >> 16, j = tx & 0xFFFFu;
+    const uint32_t ch = cand_y(i, j);
+    bool dup = false;                                                  // :778-779
+    unsigned long long match = __ballot(lane < l && ay == ch);        // different fingerprint => different message
+    while (match && !dup) {
+      const uint32_t a = (uint32_t)__builtin_ctzll(match);
+      match &= match - 1;
+      const uint32_t asrc = rdu(ax, a);
+      uint32_t diff = 0;
+      if (lane < Wd) diff = word_of(i, j, lane) ^ word_of(asrc >> 16, asrc & 0xFFFFu, lane);
+      dup = __ballot(diff != 0) == 0ull;
+    }
+    if (!dup) { wrf(as, l, ts); wru(ay, l, ch); wru(ax, l, tx); ++l; }   // :780-783
+    if (j == L - 1) continue;                                          // :788
+    const float nxt = cand_s(i, j + 1);
+    if (nxt != NEG) {                                                  // :790-796
+      sift_up(hn, 0, nxt + rdf(addv, i), (i << 16) | (j + 1));
+      ++hn;
+    }
+  }
+  // 3. outputs: lane a writes list entry a (:781, :799) and, if accepted, its message
+  if (lane < L) {
+    *reinterpret_cast<uint2*>(cur + own_sh + lane * sBlk) = lane < l ? make_uint2(f2u(as), ay) : make_uint2(kNegInfBits, 0u);
+    if (lane < l)
+      for (uint32_t w = 0; w < Wd; ++w)
+        cur[tg.own + lane * sBlk + 2 * g.N + msg_word_off(g.N, tg.c, w, tg.np_dst)] = word_of(ax >> 16, ax & 0xFFFFu, w);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // fast kernel
 // ---------------------------------------------------------------------------------------
 namespace {
@@ -862,6 +1010,15 @@ int launch_step_exact(const StepArgs& a, const Geometry& g, const DevCode* codes
   hipLaunchKernelGGL(lva_step_exact, grid, block, 0, (hipStream_t)stream, a, g, codes, trellis);
   return (int)hipGetLastError();
 }
+
+int launch_step_wave(const StepArgs& a, const Geometry& g, const DevCode* codes, uint32_t* trellis, void* stream) {
+  if (a.nslots == 0 || a.band_max == 0) return 0;
+  dim3 grid((g.N + 3) / 4, a.band_max * 8, a.nslots), block(256);
+  hipLaunchKernelGGL(lva_step_wave, grid, block, 0, (hipStream_t)stream, a, g, codes, trellis);
+  return (int)hipGetLastError();
+}
+
+bool wave_kernel_available(const Geometry& g) { return g.L >= 2 && g.L <= 64; }
 
 bool fast_kernel_available(const Geometry& g) {
   const bool l_ok = g.L == 1 || g.L == 2 || g.L == 4 || g.L == 8;

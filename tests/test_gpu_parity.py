@@ -48,7 +48,13 @@ def test_fast_kernel_matches_oracle(oracle, m, r, msg_len, L, md, n, margin, rc_
     _compare(oracle, m, r, msg_len, L, md, reads, kernel=2)
 
 
-@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("m,r,msg_len,L,md,n,margin,rc_mode", [c for c in CASES if c[3] >= 2])
+def test_wave_kernel_matches_oracle(oracle, m, r, msg_len, L, md, n, margin, rc_mode):
+    reads = synth.make_reads(m, r, msg_len, n, seed0=100 * m + r, rc_mode=rc_mode, margin=margin)
+    _compare(oracle, m, r, msg_len, L, md, reads, kernel=3)
+
+
+@pytest.mark.parametrize("kernel", [1, 2, 3])
 def test_tie_stress(oracle, kernel):
     """posteriors on a 0.25 grid: exact fp32 score ties everywhere, libstdc++ heap order decides"""
     reads = synth.make_reads(6, 1, 60, 4, seed0=7, rc_mode="odd", margin=3.0, quantum=0.25)
@@ -71,7 +77,7 @@ def test_minus_inf_posteriors(oracle):
         p = x["post"].copy()
         p[rng.random(p.shape) < 0.02] = -np.inf
         x["post"] = p
-    for kernel in (1, 2):
+    for kernel in (1, 2, 3):
         _compare(oracle, 6, 1, 60, 4, 20, reads, kernel=kernel)
 
 
@@ -104,7 +110,7 @@ def test_work_list_overflow_falls_back_to_the_exact_step(oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("md", [0, 1, 2])
-@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("kernel", [1, 2, 3])
 def test_tiny_bands(oracle, md, kernel):
     """max_deviation 0 (empty band: the reference writes an empty list), 1 and 2 (ring of 3 / 5 positions)"""
     reads = synth.make_reads(6, 1, 24, 3, seed0=77, rc_mode="odd", margin=5.0)
@@ -115,3 +121,11 @@ def test_tiny_bands(oracle, md, kernel):
 def test_m11_variants(oracle, m, r, msg_len, L, rc, sync):
     reads = [synth.make_read(m, r, msg_len, 400 + i, rc=rc, margin=3.5) for i in range(2)]
     _compare(oracle, m, r, msg_len, L, 20, reads, kernel=0, sync_marker=sync, sync_period=12 if sync else 0)
+
+
+@pytest.mark.parametrize("L", [3, 16, 33, 64])
+def test_long_and_odd_lists_use_the_wave_kernel(oracle, L):
+    reads = synth.make_reads(8, 3, 44, 3, seed0=600 + L, rc_mode="odd", margin=3.0)
+    with pkg.Decoder(8, 3, 44, list_size=L, max_deviation=20) as dec:
+        assert dec.profile()["kernel"] == 3
+    _compare(oracle, 8, 3, 44, L, 20, reads, kernel=0)
