@@ -129,3 +129,14 @@ def test_long_and_odd_lists_use_the_wave_kernel(oracle, L):
     with pkg.Decoder(8, 3, 44, list_size=L, max_deviation=20) as dec:
         assert dec.profile()["kernel"] == 3
     _compare(oracle, 8, 3, 44, L, 20, reads, kernel=0)
+
+
+def test_many_short_reads_through_few_slots(oracle):
+    """200 reads of different lengths through 5 slots: slot turnover, stale ring contents, mixed orientations"""
+    reads = [synth.make_read(6, 1, 24, 5000 + i, rc=bool(i % 3 == 0), margin=3.0 + (i % 4)) for i in range(200)]
+    with pkg.Decoder(6, 1, 24, list_size=4, max_deviation=6, max_slots=5) as dec:
+        got = dec.decode([x["post"] for x in reads], rc=[x["rc"] for x in reads])
+    codes = {rc: oracle.OracleCode(6, 1, 24, rc=rc) for rc in (False, True)}
+    for x, g in zip(reads, got):
+        wm, ws = codes[x["rc"]].decode(x["post"], 4, 6)
+        assert np.array_equal(g[0], wm) and np.array_equal(g[1].view(np.uint32), ws.view(np.uint32))
