@@ -802,29 +802,41 @@ __device__ __forceinline__ int fast_merge(const Geometry& g, const uint32_t* __r
   // every fingerprint match filed under the entry must be the same message, else the exact
   // path redoes the target
   bool good = true;
+  constexpr int GB = LL >= 4 ? 4 : LL;       // entries whose loads are in flight together (8: 86 VGPRs, slower)
 #pragma unroll
-  for (int l = 0; l < LL; ++l) {
-    if ((uint32_t)l < lc) {
-      const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu;
-      const uint32_t i = a8 >> 3, j = a8 & 7u;
-      const uint32_t from = i == 0 ? own + mul24(j, sBlk) : src + mul24(list_crf(k, i), sCrf) + mul24(j, sBlk);
-      uint32_t m[2 * P];
-      load_msg<P>(prev + from + pw, N, i == 0 ? c : cp, i == 0 ? np_dst : np_src, m);
-      push_bits<2 * P>(m, i == 0 ? 0u : sh, nb);
-      store_msg<P>(cur + own + l * sBlk + pw, N, c, np_dst, m);
-      const uint32_t r0 = (uint32_t)(rej0 >> (7 * l)) & 0x7Fu;
-      if (r0) {
+  for (int l0 = 0; l0 < LL; l0 += GB) {
+    uint32_t m[GB][2 * P];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const uint32_t rec = s ? (uint32_t)(rej1 >> (7 * l)) & 0x7Fu : r0;
-          if (rec & 0x40u) {
-            const uint32_t ri = (rec >> 3) & 7u, rj = rec & 7u;
-            const uint32_t rfrom = ri == 0 ? own + mul24(rj, sBlk) : src + mul24(list_crf(k, ri), sCrf) + mul24(rj, sBlk);
-            uint32_t qm[2 * P];
-            load_msg<P>(prev + rfrom + pw, N, ri == 0 ? c : cp, ri == 0 ? np_dst : np_src, qm);
-            push_bits<2 * P>(qm, ri == 0 ? 0u : sh, nb);
+    for (int u = 0; u < GB; ++u) {
+      const int l = l0 + u;
+      if ((uint32_t)l < lc) {
+        const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu;
+        const uint32_t i = a8 >> 3, j = a8 & 7u;
+        const uint32_t from = i == 0 ? own + mul24(j, sBlk) : src + mul24(list_crf(k, i), sCrf) + mul24(j, sBlk);
+        load_msg<P>(prev + from + pw, N, i == 0 ? c : cp, i == 0 ? np_dst : np_src, m[u]);
+      }
+    }
 #pragma unroll
-            for (int w = 0; w < 2 * P; ++w) good &= (qm[w] == m[w]);
+    for (int u = 0; u < GB; ++u) {
+      const int l = l0 + u;
+      if ((uint32_t)l < lc) {
+        const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu;
+        push_bits<2 * P>(m[u], (a8 >> 3) == 0 ? 0u : sh, nb);
+        store_msg<P>(cur + own + l * sBlk + pw, N, c, np_dst, m[u]);
+        const uint32_t r0 = (uint32_t)(rej0 >> (7 * l)) & 0x7Fu;
+        if (r0) {
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const uint32_t rec = s2 ? (uint32_t)(rej1 >> (7 * l)) & 0x7Fu : r0;
+            if (rec & 0x40u) {
+              const uint32_t ri = (rec >> 3) & 7u, rj = rec & 7u;
+              const uint32_t rfrom = ri == 0 ? own + mul24(rj, sBlk) : src + mul24(list_crf(k, ri), sCrf) + mul24(rj, sBlk);
+              uint32_t qm[2 * P];
+              load_msg<P>(prev + rfrom + pw, N, ri == 0 ? c : cp, ri == 0 ? np_dst : np_src, qm);
+              push_bits<2 * P>(qm, ri == 0 ? 0u : sh, nb);
+#pragma unroll
+              for (int w = 0; w < 2 * P; ++w) good &= (qm[w] == m[u][w]);
+            }
           }
         }
       }
