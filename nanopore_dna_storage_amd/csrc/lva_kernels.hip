@@ -452,27 +452,16 @@ __global__ __launch_bounds__(256) void lva_step_fixup(StepArgs args, Geometry g,
 }
 
 // ---------------------------------------------------------------------------------------
-// wave kernel: the literal reference merge with ONE WAVEFRONT PER TARGET, for list sizes
-// 2 <= L <= 64 that have no fast kernel (L = 16, 32, 64, odd sizes).  Lane j holds entry j of
-// each of the target's <= 8 candidate lists (8 registers), heap element e lives in lane e,
-// accepted entry a in lane a; the merge itself is wavefront-uniform (v_readlane), the
+// The literal reference merge of ONE target by ONE WAVEFRONT, list sizes 2 <= L <= 64.  Lane j
+// holds entry j of each of the target's <= 8 candidate lists (8 registers), heap element e lives
+// in lane e, accepted entry a in lane a; the merge itself is wavefront-uniform (v_readlane), the
 // de-duplication scan over the accepted fingerprints is ONE ballot instead of a loop over L
 // entries, and all loads/stores of list entries are spread over the lanes.
-// grid: x = groups of 4 conv states, y = band position index * 8 + crf state, z = slot.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lva_step_wave(StepArgs args, Geometry g, const DevCode* __restrict__ codes,
-                                                     uint32_t* __restrict__ trellis) {
-  const SlotStep& ss = args.s[blockIdx.z];
-  const uint32_t pos = ss.lo + (blockIdx.y >> 3), k = blockIdx.y & 7u;
-  if (pos >= ss.hi) return;
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const DevCode& cd = codes[ss.orient];
-  if (c >= cd.nconv) return;
-  const uint32_t* prev; uint32_t* cur;
-  slot_buffers(ss, g, trellis, &prev, &cur);
-  Target tg;
-  if (!resolve_target(cd, g, ss, pos, c, k, &tg)) return;              // (uniform per wavefront)
+namespace {
+__device__ __forceinline__ void wave_target(const Geometry& g, const SlotStep& ss, const uint32_t* __restrict__ prev,
+                                            uint32_t* __restrict__ cur, const Target& tg, uint32_t pos, uint32_t lane) {
+  const uint32_t k = tg.k;
   const uint32_t L = g.L, sBlk = g.sBlk, sCrf = (uint32_t)g.sCrf;
   const uint32_t Wd = 2 * tg.np_dst;
   const float NEG = -INFINITY;
@@ -594,6 +583,62 @@ __global__ __launch_bounds__(256) void lva_step_wave(StepArgs args, Geometry g, 
     if (lane < l)
       for (uint32_t w = 0; w < Wd; ++w)
         cur[tg.own + lane * sBlk + 2 * g.N + msg_word_off(g.N, tg.c, w, tg.np_dst)] = word_of(ax >> 16, ax & 0xFFFFu, w);
+  }
+}
+}  // namespace
+
+// wave kernel: wave_target over the whole step -- kernel mode 3.
+// grid: x = groups of 4 conv states, y = band position index * 8 + crf state, z = slot.
+__global__ __launch_bounds__(256) void lva_step_wave(StepArgs args, Geometry g, const DevCode* __restrict__ codes,
+                                                     uint32_t* __restrict__ trellis) {
+  const SlotStep& ss = args.s[blockIdx.z];
+  const uint32_t pos = ss.lo + (blockIdx.y >> 3), k = blockIdx.y & 7u;
+  if (pos >= ss.hi) return;
+  const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const DevCode& cd = codes[ss.orient];
+  if (c >= cd.nconv) return;
+  const uint32_t* prev; uint32_t* cur;
+  slot_buffers(ss, g, trellis, &prev, &cur);
+  Target tg;
+  if (!resolve_target(cd, g, ss, pos, c, k, &tg)) return;              // (uniform per wavefront)
+  wave_target(g, ss, prev, cur, tg, pos, threadIdx.x & 63u);
+}
+
+// fix-up pass behind the big-list fast kernel (8 < L <= 64, and list sizes that are not a power of
+// two): wave_target over the work list; same item format and overflow behaviour as lva_step_fixup.
+__global__ __launch_bounds__(256) void lva_step_fixup_wave(StepArgs args, Geometry g, const DevCode* __restrict__ codes,
+                                                           uint32_t* __restrict__ trellis, WorkHdr* __restrict__ hdr,
+                                                           const uint32_t* __restrict__ items) {
+  const uint32_t par = args.step_parity;
+  const uint32_t n = hdr->count[par] < hdr->cap ? hdr->count[par] : hdr->cap;
+  const bool all = hdr->overflow[par] != 0;
+  if (n == 0 && !all) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&hdr->total, (unsigned long long)(all ? 0xFFFFFFFFu : n));
+  Target tg;
+  if (all) {   // work list overflowed: redo the whole step, one thread per target
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    const uint64_t per_slot = (uint64_t)args.band_max * g.N * 8, total = per_slot * args.nslots;
+    for (uint64_t idx = gid; idx < total; idx += stride) {
+      const uint32_t si = (uint32_t)(idx / per_slot);
+      const uint32_t rem = (uint32_t)(idx % per_slot);
+      const SlotStep& ss = args.s[si];
+      const uint32_t c = rem % g.N, k = (rem / g.N) & 7u, pos = ss.lo + rem / (g.N * 8);
+      if (pos >= ss.hi) continue;
+      const uint32_t* prev; uint32_t* cur;
+      slot_buffers(ss, g, trellis, &prev, &cur);
+      if (resolve_target(codes[ss.orient], g, ss, pos, c, k, &tg)) exact_state(g, ss, prev, cur, tg, pos);
+    }
+    return;
+  }
+  const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u, nwaves = gridDim.x * 4;
+  for (uint32_t idx = blockIdx.x * 4 + wv; idx < n; idx += nwaves) {
+    const uint32_t it = items[idx];
+    const SlotStep& ss = args.s[it >> 25];
+    const uint32_t pos = ss.lo + ((it >> 17) & 0xFFu), k = (it >> 14) & 7u, c = it & 0x3FFFu;
+    const uint32_t* prev; uint32_t* cur;
+    slot_buffers(ss, g, trellis, &prev, &cur);
+    if (!resolve_target(codes[ss.orient], g, ss, pos, c, k, &tg)) continue;   // (uniform per wavefront)
+    wave_target(g, ss, prev, cur, tg, pos, lane);
   }
 }
 
@@ -879,6 +924,57 @@ __device__ __forceinline__ void fast_acs(const Geometry& g, const uint32_t* __re
   }
 }
 
+// The butterfly: thread tid of the workgroup that owns source tile `tile` (TSx consecutive source
+// conv states at pos-1) -> its target state at pos.  Thread = (role, base r, target conv): role 0
+// merges the flip target of its (conv, base), role 1 the flop target.  False: nothing to do.
+struct TileTarget {
+  uint32_t c, cp, sc;            // target conv, source conv, source conv relative to the tile
+  uint32_t k, sh, nb, fpc;       // target crf state; message shift, new bits and fingerprint delta of the step
+  uint32_t np_dst, np_src;
+  uint32_t ok;                   // bit i: list i exists (bit 0 = stay)
+  uint32_t own;                  // word offset of block (ring(pos), k, l=0)
+};
+template <uint32_t TSx>
+__device__ __forceinline__ bool tile_target(const DevCode& cd, const Geometry& g, const SlotStep& ss, uint32_t pos,
+                                            uint32_t tile, uint32_t tid, TileTarget* t) {
+  const uint32_t N = cd.nconv;
+  const uint32_t T = cd.ptype[pos], sh = T == 0 ? 1u : 2u;
+  const uint32_t Tn = TSx >> sh;                         // target conv states per butterfly leg
+  const uint32_t role = tid / (4 * TSx), r = (tid / TSx) & 3u, tcl = tid % TSx;
+  const uint32_t c = tile * Tn + (tcl & (Tn - 1)) + (tcl / Tn) * (N >> sh);
+  if ((c & cd.vmask[pos]) != cd.vval[pos]) return false;  // :700
+  const uint32_t pk = cd.predtab[T][c];
+  uint32_t base = r;
+  if (T == 0) {                                          // only two bases are reachable: r-th of them
+    if (r >= 2) return false;
+    const uint32_t has = ((pk >> 3) & 1u) | (((pk >> 7) & 1u) << 1) | (((pk >> 11) & 1u) << 2) | (((pk >> 15) & 1u) << 3);
+    if ((uint32_t)__builtin_popcount(has) <= r) return false;
+    const uint32_t first = __builtin_ctz(has);
+    base = r == 0 ? first : __builtin_ctz(has & ~(1u << first));
+  }
+  const uint32_t nib = (pk >> (4 * base)) & 0xFu;
+  if (!(nib & 8u)) return false;
+  const uint32_t cp = ((c << sh) | (nib & 7u)) & (N - 1);
+  const uint32_t newest = c >> (cd.m - 1), second = (c >> (cd.m - 2)) & 1u;
+  t->c = c; t->cp = cp; t->sc = cp - tile * TSx; t->sh = sh;
+  t->nb = sh == 1 ? newest : (2 * second + newest);
+  t->fpc = cd.fpc[pos][t->nb];
+  t->np_dst = cd.npair[pos]; t->np_src = cd.npair[pos - 1];
+  const uint32_t reach = source_reach(cd, ss, pos, cp);
+  const uint32_t k = base + 4 * role;
+  t->k = k;
+  t->own = (uint32_t)(((uint64_t)(pos % g.R) * 8 + k) * g.sCrf);
+  uint32_t ok = pos < ss.prev_hi ? 1u : 0u;
+  if (role == 0) {
+#pragma unroll
+    for (uint32_t i = 1; i < 8; ++i) ok |= ((reach >> list_crf(k, i)) & 1u) << i;
+  } else {
+    ok |= ((reach >> base) & 1u) << 1;
+  }
+  t->ok = ok;
+  return true;
+}
+
 }  // namespace
 
 // grid: x = tiles of 64 source conv states, y = band position index, z = slot index.
@@ -927,47 +1023,241 @@ __global__ __launch_bounds__(8 * TS) void lva_step_fast(StepArgs args, Geometry 
   __syncthreads();
 
   // ---- this thread's (role, target conv, base) ----
-  const uint32_t T = cd.ptype[pos], sh = T == 0 ? 1u : 2u;
-  const uint32_t Tn = TS >> sh;                          // target conv states per butterfly leg
-  const uint32_t role = tid / (4 * TS), r = (tid / TS) & 3u, tcl = tid % TS;
-  const uint32_t c = tile * Tn + (tcl & (Tn - 1)) + (tcl / Tn) * (N >> sh);
-  if ((c & cd.vmask[pos]) != cd.vval[pos]) return;       // :700
-  const uint32_t pk = cd.predtab[T][c];
-  uint32_t base = r;
-  if (T == 0) {                                          // only two bases are reachable: r-th of them
-    if (r >= 2) return;
-    const uint32_t has = ((pk >> 3) & 1u) | (((pk >> 7) & 1u) << 1) | (((pk >> 11) & 1u) << 2) | (((pk >> 15) & 1u) << 3);
-    if ((uint32_t)__builtin_popcount(has) <= r) return;
-    const uint32_t first = __builtin_ctz(has);
-    base = r == 0 ? first : __builtin_ctz(has & ~(1u << first));
-  }
-  const uint32_t nib = (pk >> (4 * base)) & 0xFu;
-  if (!(nib & 8u)) return;
-  const uint32_t cp = ((c << sh) | (nib & 7u)) & (N - 1);
-  const uint32_t sc = cp - tile * TS;
-  const uint32_t newest = c >> (cd.m - 1), second = (c >> (cd.m - 2)) & 1u;
-  const uint32_t nb = sh == 1 ? newest : (2 * second + newest);
-  const uint32_t fpc = cd.fpc[pos][nb];
-  const uint32_t np_dst = cd.npair[pos], np_src = cd.npair[pos - 1];
-  const uint32_t reach = source_reach(cd, ss, pos, cp);
-  const uint32_t k = base + 4 * role;
-  const uint32_t own = (uint32_t)(((uint64_t)(pos % g.R) * 8 + k) * g.sCrf);
-  uint32_t ok = pos < ss.prev_hi ? 1u : 0u;
+  TileTarget t;
+  if (!tile_target<TS>(cd, g, ss, pos, tile, tid, &t)) return;
   int why;
-  if (role == 0) {
-#pragma unroll
-    for (uint32_t i = 1; i < 8; ++i) ok |= ((reach >> list_crf(k, i)) & 1u) << i;
-    if constexpr (LL == 1) { fast_acs<P, 8>(g, prev, cur, s_src, s_post, k, c, cp, sc, own, src, ok, sh, nb, fpc, np_dst, np_src); why = 0; }
-    else why = fast_merge<LL, P, 8>(g, prev, cur, s_src, s_post, k, c, cp, sc, own, src, ok, sh, nb, fpc, np_dst, np_src);
+  if (t.k < 4) {
+    if constexpr (LL == 1) { fast_acs<P, 8>(g, prev, cur, s_src, s_post, t.k, t.c, t.cp, t.sc, t.own, src, t.ok, t.sh, t.nb, t.fpc, t.np_dst, t.np_src); why = 0; }
+    else why = fast_merge<LL, P, 8>(g, prev, cur, s_src, s_post, t.k, t.c, t.cp, t.sc, t.own, src, t.ok, t.sh, t.nb, t.fpc, t.np_dst, t.np_src);
   } else {
-    ok |= ((reach >> base) & 1u) << 1;
-    if constexpr (LL == 1) { fast_acs<P, 2>(g, prev, cur, s_src, s_post, k, c, cp, sc, own, src, ok, sh, nb, fpc, np_dst, np_src); why = 0; }
-    else why = fast_merge<LL, P, 2>(g, prev, cur, s_src, s_post, k, c, cp, sc, own, src, ok, sh, nb, fpc, np_dst, np_src);
+    if constexpr (LL == 1) { fast_acs<P, 2>(g, prev, cur, s_src, s_post, t.k, t.c, t.cp, t.sc, t.own, src, t.ok, t.sh, t.nb, t.fpc, t.np_dst, t.np_src); why = 0; }
+    else why = fast_merge<LL, P, 2>(g, prev, cur, s_src, s_post, t.k, t.c, t.cp, t.sc, t.own, src, t.ok, t.sh, t.nb, t.fpc, t.np_dst, t.np_src);
   }
+  const uint32_t k = t.k, c = t.c;
   if (why) {
     atomicAdd(&hdr->reason[why - 1], 1ull);
     const uint32_t idx = atomicAdd(&hdr->count[args.step_parity], 1u);
     if (idx < hdr->cap) items[idx] = (blockIdx.z << 25) | (blockIdx.y << 17) | (k << 14) | c;
+    else hdr->overflow[args.step_parity] = 1u;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// big-list fast kernel: list sizes 2 <= L <= 64 that lva_step_fast has no instance for
+// (LL = 16, 32 or 64 >= L is the compile-time capacity).  Same butterfly tiling and the same
+// one-target-per-thread tournament, but a list of 64 entries per state does not fit LDS or
+// registers, so:
+//   * list heads are read from HBM/L2 on demand -- one 8-byte (score, fingerprint) load per pop,
+//     issued before the de-duplication scan that hides most of its latency;
+//   * the only per-entry register state is the accepted fingerprints (LL registers); where each
+//     accepted entry came from (list, index: 9 bits) and the fingerprint matches that still have to
+//     be verified against it (at most two: a message can sit in at most three lists -- stay, flip X
+//     and flop X of the base it ends in) go to LDS, one byte each, plus one bit each in registers;
+//   * nothing is written inside the merge loop: afterwards all lanes walk the output rows in
+//     lockstep -- entry l of 64 neighbouring conv states at a time -- re-read the source entry,
+//     recompute score + transition exactly as the merge did, and store full 512-byte rows.
+// Ties, non-finite sums, a third fingerprint match on one entry and fingerprint collisions send the
+// target to lva_step_fixup_wave.
+// ---------------------------------------------------------------------------------------
+namespace {
+
+constexpr uint32_t TSB = 32;       // source conv states per workgroup tile (workgroup = 8*TSB = 256 threads)
+
+template <int LL, int P, int NL>
+__device__ __forceinline__ int big_merge(const Geometry& g, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur,
+                                          const float* s_post, uint8_t* s_acc, uint8_t* s_rej0, uint8_t* s_rej1,
+                                          const TileTarget& t, uint32_t src) {
+  constexpr uint32_t NT = 8 * TSB;
+  const float NEG = -INFINITY;
+  const uint32_t L = g.L, N = g.N, sBlk = g.sBlk, sCrf = (uint32_t)g.sCrf, pw = 2 * g.N;
+  const uint32_t k = t.k, row = k >= 4 ? 4u : k;
+  const uint32_t own_c = t.own + 2 * t.c, src_c = src + 2 * t.cp;
+  // word offset of the (score, fingerprint) pair of entry 0 of list i; its transition score
+  auto lbase = [&](uint32_t i) -> uint32_t { return i == 0 ? own_c : src_c + mul24(list_crf(k, i), sCrf); };
+  auto ladd = [&](uint32_t i) -> float { return s_post[row * 8 + (i == 0 ? k : list_crf(k, i))]; };
+  int why = 0;
+
+  // list heads (:750-761)
+  float h[NL]; uint32_t hf[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    h[i] = NEG; hf[i] = 0;
+    if ((t.ok >> i) & 1u) {
+      const uint2 v = *reinterpret_cast<const uint2*>(prev + lbase(i));
+      const bool ok = u2f(v.x) != NEG;
+      h[i] = ok ? u2f(v.x) + ladd(i) : NEG;
+      if (ok && !(h[i] > NEG)) why = 2;                  // non-finite sum: the exact path decides
+      hf[i] = i ? v.y ^ t.fpc : v.y;
+    }
+  }
+
+  uint32_t ah[LL];                 // accepted fingerprints, NEWEST FIRST (shift register: static indices only)
+#pragma unroll
+  for (int l = 0; l < LL; ++l) ah[l] = 0;
+  unsigned long long ptr = 0;      // 7 bits per list: entries consumed
+  // (list << 6 | index) of accepted entry a: low byte in s_acc[a], bit 8 in bit a of acc_hi.  The same
+  // for the <= 2 fingerprint matches filed under entry a: s_rej0/1[a], rh0/1, and rv0/1 = slot in use.
+  unsigned long long acc_hi = 0, rv0 = 0, rv1 = 0, rh0 = 0, rh1 = 0;
+  uint32_t lc = 0;
+
+  bool go = why == 0;
+  while (go) {                                                         // :764
+    float M = h[0];
+#pragma unroll
+    for (int i = 1; i < NL; ++i) M = fmaxf(M, h[i]);
+    bool eq[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) eq[i] = h[i] == M;
+    uint32_t sel = NL - 1, last = 0;   // first / last head equal to the maximum: they differ on a tie
+#pragma unroll
+    for (int i = NL - 2; i >= 0; --i) sel = eq[i] ? (uint32_t)i : sel;
+#pragma unroll
+    for (int i = 1; i < NL; ++i) last = eq[i] ? (uint32_t)i : last;
+    const bool two = sel != last;
+    const bool alive = M > NEG;            // false: every list exhausted (heap empty)
+    const bool proceed = alive && !two;
+    const uint32_t j = (uint32_t)(ptr >> (7 * sel)) & 127u;
+    // next entry of the popped list: issue the load now, use it after the scan below (:788-796)
+    const bool has_next = j + 1 < L;
+    const uint32_t lb = lbase(sel);
+    const uint2 nv = *reinterpret_cast<const uint2*>(prev + lb + mul24(has_next ? j + 1 : j, sBlk));
+    uint32_t ch = hf[NL - 1];
+#pragma unroll
+    for (int i = NL - 2; i >= 0; --i) ch = selv(eq[i], hf[i], ch);
+    // de-duplicate on fingerprints (:778-779): position q in ah <-> accepted entry lc-1-q
+    int q = -1;
+#pragma unroll
+    for (int a = LL - 1; a >= 0; --a) q = ah[a] == ch ? a : q;
+    const bool isdup = q >= 0 && (uint32_t)q < lc;
+    const bool accept = proceed && !isdup, reject = proceed && isdup;
+    const uint32_t from9 = (sel << 6) | j;
+    const unsigned long long hi9 = (unsigned long long)(sel >> 2);
+    if (accept) s_acc[lc * NT] = (uint8_t)from9;
+    acc_hi |= accept ? hi9 << lc : 0ull;
+    const uint32_t ra = lc - 1u - (uint32_t)q;                 // the entry it matched (only meaningful when reject)
+    const unsigned long long rbit = 1ull << (ra & 63u);
+    const bool use0 = reject && !(rv0 & rbit), use1 = reject && !use0 && !(rv1 & rbit), rej_full = reject && !use0 && !use1;
+    if (use0) s_rej0[ra * NT] = (uint8_t)from9;
+    if (use1) s_rej1[ra * NT] = (uint8_t)from9;
+    rv0 |= use0 ? rbit : 0ull; rh0 |= (use0 && hi9) ? rbit : 0ull;
+    rv1 |= use1 ? rbit : 0ull; rh1 |= (use1 && hi9) ? rbit : 0ull;
+#pragma unroll
+    for (int a = LL - 1; a >= 1; --a) ah[a] = selv(accept, ah[a - 1], ah[a]);
+    ah[0] = selv(accept, ch, ah[0]);
+    lc += accept ? 1u : 0u;
+    // advance the popped list
+    const float addsel = ladd(sel);
+    const bool nxt_ok = has_next && u2f(nv.x) != NEG;
+    const float ns = nxt_ok ? u2f(nv.x) + addsel : NEG;
+    const bool bad = nxt_ok && !(ns > NEG);   // overflowed to -inf: the reference would still queue it
+    const uint32_t nf = sel ? nv.y ^ t.fpc : nv.y;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) { h[i] = selv(eq[i], ns, h[i]); hf[i] = selv(eq[i], nf, hf[i]); }
+    ptr += 1ull << (7 * sel);
+    why = (alive && two) ? 1 : ((proceed && bad) ? 2 : (rej_full ? 3 : 0));
+    go = proceed && why == 0 && lc < L;
+  }
+  if (why) return why;
+
+  // where entry `from9` of the previous step lives: message region base, conv state, planes in use
+  auto locate = [&](uint32_t from9, uint32_t* i_out) -> uint32_t {
+    const uint32_t i = from9 >> 6, j = from9 & 63u;
+    *i_out = i;
+    return (i == 0 ? t.own : src + mul24(list_crf(k, i), sCrf)) + mul24(j, sBlk);
+  };
+  // outputs, entry l of the whole wavefront at a time (:771-774, :780-783, :799).  Every fingerprint
+  // match filed under an entry must be the same message (else: collision, the exact path decides).
+  bool good = true;
+  constexpr uint32_t GB = 4;       // entries whose loads are in flight together
+  for (uint32_t l0 = 0; l0 < L; l0 += GB) {
+    uint32_t m[GB][2 * P]; uint2 sh2[GB]; uint32_t iu[GB];
+#pragma unroll
+    for (uint32_t u = 0; u < GB; ++u) {
+      const uint32_t l = l0 + u;
+      iu[u] = 0; sh2[u] = make_uint2(kNegInfBits, 0u);
+      if (l < lc) {
+        const uint32_t f = locate((uint32_t)s_acc[l * NT] | ((uint32_t)(acc_hi >> l) & 1u) << 8, &iu[u]);
+        const uint32_t cv = iu[u] == 0 ? t.c : t.cp;
+        sh2[u] = *reinterpret_cast<const uint2*>(prev + f + 2 * cv);
+        load_msg<P>(prev + f + pw, N, cv, iu[u] == 0 ? t.np_dst : t.np_src, m[u]);
+      }
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < GB; ++u) {
+      const uint32_t l = l0 + u;
+      if (l < lc) {
+        const float sc = u2f(sh2[u].x) + ladd(iu[u]);
+        *reinterpret_cast<uint2*>(cur + own_c + mul24(l, sBlk)) = make_uint2(f2u(sc), iu[u] ? sh2[u].y ^ t.fpc : sh2[u].y);
+        push_bits<2 * P>(m[u], iu[u] == 0 ? 0u : t.sh, t.nb);
+        store_msg<P>(cur + t.own + mul24(l, sBlk) + pw, N, t.c, t.np_dst, m[u]);
+        if ((rv0 >> l) & 1ull) {
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            if (((s2 ? rv1 : rv0) >> l) & 1ull) {
+              uint32_t ir;
+              const uint32_t fr = locate((uint32_t)(s2 ? s_rej1 : s_rej0)[l * NT] | ((uint32_t)((s2 ? rh1 : rh0) >> l) & 1u) << 8, &ir);
+              uint32_t qm[2 * P];
+              load_msg<P>(prev + fr + pw, N, ir == 0 ? t.c : t.cp, ir == 0 ? t.np_dst : t.np_src, qm);
+              push_bits<2 * P>(qm, ir == 0 ? 0u : t.sh, t.nb);
+#pragma unroll
+              for (int w = 0; w < 2 * P; ++w) good &= (qm[w] == m[u][w]);
+            }
+          }
+        }
+      } else if (l < L) {
+        *reinterpret_cast<uint2*>(cur + own_c + mul24(l, sBlk)) = make_uint2(kNegInfBits, 0u);
+      }
+    }
+  }
+  return good ? 0 : 4;
+}
+
+}  // namespace
+
+// grid: x = tiles of TSB source conv states, y = band position index, z = slot index; 256 threads.
+template <int LL, int P>
+__global__ __launch_bounds__(8 * TSB) void lva_step_big(StepArgs args, Geometry g, const DevCode* __restrict__ codes,
+                                                      uint32_t* __restrict__ trellis, WorkHdr* __restrict__ hdr,
+                                                      uint32_t* __restrict__ items) {
+  __shared__ uint8_t s_acc[LL * 8 * TSB], s_rej0[LL * 8 * TSB], s_rej1[LL * 8 * TSB];
+  __shared__ float s_post[40];
+  const SlotStep& ss = args.s[blockIdx.z];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+    hdr->count[args.step_parity ^ 1u] = 0;     // the other parity's list was consumed by the last fix-up
+    hdr->overflow[args.step_parity ^ 1u] = 0;
+  }
+  const uint32_t pos = ss.lo + blockIdx.y;
+  if (pos >= ss.hi) return;
+  const DevCode& cd = codes[ss.orient];
+  const uint32_t N = cd.nconv, tid = threadIdx.x, tile = blockIdx.x;
+  const uint32_t* prev; uint32_t* cur;
+  slot_buffers(ss, g, trellis, &prev, &cur);
+
+  if (pos == 0) {                          // stay-only update of the 8 start states (:706-713)
+    if (tile == cd.init / TSB && tid < 8) {
+      const uint32_t k = tid, c = cd.init;
+      const uint32_t own_c = (uint32_t)((uint64_t)k * g.sCrf) + 2 * c;
+      const float s = u2f(prev[own_c]) + ss.post_row[(k >= 4 ? 4u : k) * 8 + k];
+      cur[own_c] = f2u(s);
+      cur[own_c + 1] = prev[own_c + 1];
+      cur[own_c + 2 * N] = prev[own_c + 2 * N];          // plane 1 (the only one in use at position 0)
+      cur[own_c + 2 * N + 1] = prev[own_c + 2 * N + 1];
+      for (uint32_t l = 1; l < g.L; ++l) cur[own_c + l * g.sBlk] = kNegInfBits;
+    }
+    return;
+  }
+  if (tid < 40) s_post[tid] = ss.post_row[tid];
+  __syncthreads();
+
+  const uint32_t src = (uint32_t)((uint64_t)((pos - 1) % g.R) * 8 * g.sCrf);
+  TileTarget t;
+  if (!tile_target<TSB>(cd, g, ss, pos, tile, tid, &t)) return;
+  const int why = t.k < 4 ? big_merge<LL, P, 8>(g, prev, cur, s_post, s_acc + tid, s_rej0 + tid, s_rej1 + tid, t, src)
+                          : big_merge<LL, P, 2>(g, prev, cur, s_post, s_acc + tid, s_rej0 + tid, s_rej1 + tid, t, src);
+  if (why) {
+    atomicAdd(&hdr->reason[why - 1], 1ull);
+    const uint32_t idx = atomicAdd(&hdr->count[args.step_parity], 1u);
+    if (idx < hdr->cap) items[idx] = (blockIdx.z << 25) | (blockIdx.y << 17) | (t.k << 14) | t.c;
     else hdr->overflow[args.step_parity] = 1u;
   }
 }
@@ -1032,8 +1322,10 @@ int launch_step_wave(const StepArgs& a, const Geometry& g, const DevCode* codes,
 
 bool wave_kernel_available(const Geometry& g) { return g.L >= 2 && g.L <= 64; }
 
+static bool small_list(const Geometry& g) { return g.L == 1 || g.L == 2 || g.L == 4 || g.L == 8; }
+
 bool fast_kernel_available(const Geometry& g) {
-  const bool l_ok = g.L == 1 || g.L == 2 || g.L == 4 || g.L == 8;
+  const bool l_ok = small_list(g) || (g.L >= 2 && g.L <= 64);
   return l_ok && g.P >= 1 && g.P <= 4 && g.N >= 64;
 }
 
@@ -1051,11 +1343,33 @@ static int launch_fast_p(const StepArgs& a, const Geometry& g, const DevCode* co
   return (int)hipGetLastError();
 }
 
+template <int LL>
+static int launch_big_p(const StepArgs& a, const Geometry& g, const DevCode* codes, uint32_t* trellis, WorkHdr* hdr,
+                        uint32_t* items, hipStream_t st) {
+  dim3 grid(g.N / TSB, a.band_max, a.nslots), block(8 * TSB);
+  switch (g.P) {
+    case 1: hipLaunchKernelGGL((lva_step_big<LL, 1>), grid, block, 0, st, a, g, codes, trellis, hdr, items); break;
+    case 2: hipLaunchKernelGGL((lva_step_big<LL, 2>), grid, block, 0, st, a, g, codes, trellis, hdr, items); break;
+    case 3: hipLaunchKernelGGL((lva_step_big<LL, 3>), grid, block, 0, st, a, g, codes, trellis, hdr, items); break;
+    case 4: hipLaunchKernelGGL((lva_step_big<LL, 4>), grid, block, 0, st, a, g, codes, trellis, hdr, items); break;
+    default: return (int)hipErrorInvalidValue;
+  }
+  return (int)hipGetLastError();
+}
+
 int launch_step_fast(const StepArgs& a, const Geometry& g, const DevCode* codes, uint32_t* trellis, WorkHdr* hdr,
                      uint32_t* items, void* stream) {
   if (a.nslots == 0 || a.band_max == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   int e;
+  if (!small_list(g)) {   // big-list kernel + wavefront-per-target fix-up
+    e = g.L <= 16 ? launch_big_p<16>(a, g, codes, trellis, hdr, items, st)
+      : g.L <= 32 ? launch_big_p<32>(a, g, codes, trellis, hdr, items, st)
+                  : launch_big_p<64>(a, g, codes, trellis, hdr, items, st);
+    if (e) return e;
+    hipLaunchKernelGGL(lva_step_fixup_wave, dim3(512), dim3(256), 0, st, a, g, codes, trellis, hdr, items);
+    return (int)hipGetLastError();
+  }
   switch (g.L) {
     case 1: e = launch_fast_p<1>(a, g, codes, trellis, hdr, items, st); break;
     case 2: e = launch_fast_p<2>(a, g, codes, trellis, hdr, items, st); break;

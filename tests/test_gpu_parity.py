@@ -42,7 +42,7 @@ def test_exact_kernel_matches_oracle(oracle, m, r, msg_len, L, md, n, margin, rc
     _compare(oracle, m, r, msg_len, L, md, reads, kernel=1)
 
 
-@pytest.mark.parametrize("m,r,msg_len,L,md,n,margin,rc_mode", [c for c in CASES if c[3] <= 8])
+@pytest.mark.parametrize("m,r,msg_len,L,md,n,margin,rc_mode", CASES)
 def test_fast_kernel_matches_oracle(oracle, m, r, msg_len, L, md, n, margin, rc_mode):
     reads = synth.make_reads(m, r, msg_len, n, seed0=100 * m + r, rc_mode=rc_mode, margin=margin)
     _compare(oracle, m, r, msg_len, L, md, reads, kernel=2)
@@ -79,6 +79,7 @@ def test_minus_inf_posteriors(oracle):
         x["post"] = p
     for kernel in (1, 2, 3):
         _compare(oracle, 6, 1, 60, 4, 20, reads, kernel=kernel)
+    _compare(oracle, 6, 1, 60, 16, 20, reads, kernel=2)
 
 
 @pytest.mark.parametrize("kernel", [1, 2])
@@ -123,12 +124,26 @@ def test_m11_variants(oracle, m, r, msg_len, L, rc, sync):
     _compare(oracle, m, r, msg_len, L, 20, reads, kernel=0, sync_marker=sync, sync_period=12 if sync else 0)
 
 
-@pytest.mark.parametrize("L", [3, 16, 33, 64])
-def test_long_and_odd_lists_use_the_wave_kernel(oracle, L):
+@pytest.mark.parametrize("L", [3, 7, 12, 16, 33, 64])
+def test_long_and_odd_lists_use_the_big_list_kernel(oracle, L):
     reads = synth.make_reads(8, 3, 44, 3, seed0=600 + L, rc_mode="odd", margin=3.0)
     with pkg.Decoder(8, 3, 44, list_size=L, max_deviation=20) as dec:
-        assert dec.profile()["kernel"] == 3
+        assert dec.profile()["kernel"] == 2
     _compare(oracle, 8, 3, 44, L, 20, reads, kernel=0)
+    _compare(oracle, 8, 3, 44, L, 20, reads, kernel=3)
+
+
+@pytest.mark.parametrize("L", [5, 16, 64])
+def test_big_list_kernel_tie_stress(oracle, L):
+    """quantised posteriors: equal scores everywhere, most targets go through the wavefront fix-up"""
+    reads = [synth.make_read(6, 1, 40, 900 + i, rc=bool(i & 1), margin=2.0, quantum=0.5) for i in range(2)]
+    _compare(oracle, 6, 1, 40, L, 20, reads, kernel=2)
+
+
+def test_big_list_kernel_work_list_overflow(oracle, monkeypatch):
+    monkeypatch.setenv("LVA_WORK_CAP", "4")
+    reads = [synth.make_read(6, 1, 40, 950 + i, rc=bool(i & 1), margin=2.0, quantum=0.5) for i in range(2)]
+    _compare(oracle, 6, 1, 40, 16, 20, reads, kernel=2)
 
 
 def test_many_short_reads_through_few_slots(oracle):
