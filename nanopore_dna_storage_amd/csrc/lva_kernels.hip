@@ -1061,7 +1061,10 @@ __global__ __launch_bounds__(8 * TS) void lva_step_fast(StepArgs args, Geometry 
 // ---------------------------------------------------------------------------------------
 namespace {
 
-constexpr uint32_t TSB = 32;       // source conv states per workgroup tile (workgroup = 8*TSB = 256 threads)
+#ifndef LVA_TSB
+#define LVA_TSB 32
+#endif
+constexpr uint32_t TSB = LVA_TSB;   // source conv states per workgroup tile (workgroup = 8*TSB threads)
 
 template <int LL, int P, int NL>
 __device__ __forceinline__ int big_merge(const Geometry& g, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur,
@@ -1367,7 +1370,7 @@ int launch_step_fast(const StepArgs& a, const Geometry& g, const DevCode* codes,
       : g.L <= 32 ? launch_big_p<32>(a, g, codes, trellis, hdr, items, st)
                   : launch_big_p<64>(a, g, codes, trellis, hdr, items, st);
     if (e) return e;
-    hipLaunchKernelGGL(lva_step_fixup_wave, dim3(512), dim3(256), 0, st, a, g, codes, trellis, hdr, items);
+    hipLaunchKernelGGL(lva_step_fixup_wave, dim3(4096), dim3(256), 0, st, a, g, codes, trellis, hdr, items);
     return (int)hipGetLastError();
   }
   switch (g.L) {
