@@ -131,6 +131,14 @@ int lva_decode_batch_device(lva_decoder *d, const float *post_dev, const int64_t
                             int32_t n_reads, const uint8_t *rc_flags, uint8_t *out_msgs,
                             float *out_scores, int32_t *out_counts);
 
+/* As lva_decode_batch_device, but read i is the window of n_blocks[i] blocks that starts at block
+ * first_block[i] of the resident buffer: decodes the payload windows found by
+ * lva_locate_payload_batch_device in place.
+ * replaces: helper.truncate_post_file (helper.py:212-224) + the decode call of generate_decoded_lists.py:80-89. */
+int lva_decode_windows_device(lva_decoder *d, const float *post_dev, const int64_t *first_block, const int64_t *n_blocks,
+                              int32_t n_reads, const uint8_t *rc_flags, uint8_t *out_msgs, float *out_scores,
+                              int32_t *out_counts);
+
 int lva_decoder_profile(const lva_decoder *d, lva_profile *out);
 
 /* Device helpers so that callers without a HIP binding (ctypes) can keep inputs resident. */
@@ -138,6 +146,52 @@ int lva_device_alloc(lva_decoder *d, uint64_t bytes, void **out_dev_ptr);
 int lva_device_free(lva_decoder *d, void *dev_ptr);
 int lva_device_upload(lva_decoder *d, void *dev_dst, const void *host_src, uint64_t bytes);
 int lva_device_synchronize(lva_decoder *d);
+
+/* ---------------------------------------------------------------------------------------------
+ * the step in front of the list decoder on real data -- flappie's
+ * flip-flop basecall of the posterior matrix and the barcode localisation on it, so that the
+ * whole .post -> payload window -> decoded list chain stays on the device.
+ * Posterior matrices are passed as for lva_decode_batch: one float32[blocks][40] buffer and
+ * row_offsets[n_reads+1] in blocks (row_offsets[0] = 0).
+ * ------------------------------------------------------------------------------------------- */
+
+/* Result of a barcode search for one read.
+ * replaces: the tuple returned by helper.find_barcode_pos_in_post (helper.py:157-210) and the
+ * orientation / length decision of generate_decoded_lists.py:68-79. */
+typedef struct lva_payload_pos {
+  int32_t start_pos, end_pos;   /* payload = blocks [start_pos, end_pos] of the read's matrix; -1, -1 on failure */
+  int32_t dist_start, dist_end; /* edit distance of the best start / end barcode match; INT32_MAX = the reference's np.inf */
+  int32_t rc;                   /* 1: the reverse-complement barcodes matched better (generate_decoded_lists.py:71-74) */
+  int32_t ok;                   /* 0: "Failure in barcode removing." (generate_decoded_lists.py:76) */
+} lva_payload_pos;
+
+/* Basecall: the base string flappie writes as the second fastq line and the positions it writes
+ * to --trans-output-file.
+ * replaces: decode_crf_flipflop (flappie/src/decode.c:119-204), change_positions (decode.c:66-79)
+ * and the loop of flappie/src/flappie.c:274-285.
+ * Outputs of read i start at row_offsets[i] in bases_out / trans_out (capacity row_offsets[n_reads]
+ * each; either may be NULL); nbases_out[i] = number of bases called. */
+int lva_basecall_batch(lva_decoder *d, const float *post, const int64_t *row_offsets, int32_t n_reads,
+                       char *bases_out, uint32_t *trans_out, int32_t *nbases_out);
+int lva_basecall_batch_device(lva_decoder *d, const float *post_dev, const int64_t *row_offsets, int32_t n_reads,
+                              char *bases_out, uint32_t *trans_out, int32_t *nbases_out);
+
+/* Barcode search on given basecalls (one orientation).
+ * replaces: helper.find_barcode_pos_in_post (helper.py:157-210); rc = 0, ok = (start_pos != -1).
+ * bases / trans hold the basecall and the trans-file integers of read i at
+ * [base_offsets[i], base_offsets[i+1]).  Barcodes: 1..64 characters. */
+int lva_find_barcode_batch(lva_decoder *d, const char *bases, const uint32_t *trans, const int64_t *base_offsets,
+                           int32_t n_reads, const char *start_barcode, const char *end_barcode, lva_payload_pos *out);
+
+/* Basecall + barcode search in both orientations + the choice between them.
+ * replaces: generate_decoded_lists.py:68-79 (START_BARCODE_RC = rc(end), END_BARCODE_RC = rc(start), :33-34);
+ * min_len = MEM_CONV + MSG_LEN + 1 (:76).  The caller then decodes blocks [start_pos, end_pos]
+ * with the rc flag (lva_decode_windows_device on the same resident buffer: no copy). */
+int lva_locate_payload_batch(lva_decoder *d, const float *post, const int64_t *row_offsets, int32_t n_reads,
+                             const char *start_barcode, const char *end_barcode, uint32_t min_len, lva_payload_pos *out);
+int lva_locate_payload_batch_device(lva_decoder *d, const float *post_dev, const int64_t *row_offsets, int32_t n_reads,
+                                    const char *start_barcode, const char *end_barcode, uint32_t min_len,
+                                    lva_payload_pos *out);
 
 #ifdef __cplusplus
 }

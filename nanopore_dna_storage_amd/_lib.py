@@ -20,6 +20,8 @@ EXPORTS = [
     "lva_encode", "lva_algorithmic_bytes", "lva_decoder_create", "lva_decoder_destroy",
     "lva_decode_batch", "lva_decode_batch_device", "lva_decoder_profile", "lva_device_alloc",
     "lva_device_free", "lva_device_upload", "lva_device_synchronize",
+    "lva_decode_windows_device", "lva_basecall_batch", "lva_basecall_batch_device", "lva_find_barcode_batch",
+    "lva_locate_payload_batch", "lva_locate_payload_batch_device",
 ]
 
 
@@ -60,6 +62,11 @@ class Profile(ctypes.Structure):
                 ("slots", ctypes.c_int32), ("kernel", ctypes.c_int32)]
 
 
+class PayloadPos(ctypes.Structure):
+    _fields_ = [("start_pos", ctypes.c_int32), ("end_pos", ctypes.c_int32), ("dist_start", ctypes.c_int32),
+                ("dist_end", ctypes.c_int32), ("rc", ctypes.c_int32), ("ok", ctypes.c_int32)]
+
+
 _lib = None
 
 
@@ -98,5 +105,11 @@ def load_library():
     L.lva_device_free.argtypes = [vp, vp]
     L.lva_device_upload.argtypes = [vp, vp, vp, u64]
     L.lva_device_synchronize.argtypes = [vp]
+    L.lva_decode_windows_device.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp]
+    L.lva_basecall_batch.argtypes = [vp, vp, vp, i32, vp, vp, vp]
+    L.lva_basecall_batch_device.argtypes = [vp, vp, vp, i32, vp, vp, vp]
+    L.lva_find_barcode_batch.argtypes = [vp, vp, vp, vp, i32, cp, cp, vp]
+    L.lva_locate_payload_batch.argtypes = [vp, vp, vp, i32, cp, cp, u32, vp]
+    L.lva_locate_payload_batch_device.argtypes = [vp, vp, vp, i32, cp, cp, u32, vp]
     _lib = L
     return L

@@ -22,6 +22,7 @@
 #include "lva_code.h"
 #include "lva_device.h"
 #include "lva_kernels.h"
+#include "bc_kernels.h"
 
 using namespace lva;
 
@@ -292,7 +293,7 @@ static void finish_read(const lva_decoder* d, int orient, const uint32_t* rec, u
   *out_count = (int32_t)paths.size();
 }
 
-static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* off, int32_t n, const uint8_t* rc_flags,
+static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg, const int64_t* len, int32_t n, const uint8_t* rc_flags,
                        uint8_t* out_msgs, float* out_scores, int32_t* out_counts, bool timed_total_started) {
   const Geometry& g = d->g;
   const uint32_t npos = d->code[0].npos, L = g.L;
@@ -300,13 +301,13 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* off
   // reads the reference would refuse (:600-601)
   std::vector<int32_t> order;
   for (int32_t i = 0; i < n; ++i) {
-    const int64_t nb = off[i + 1] - off[i];
-    if (nb < 0 || nb > 0xFFFFFFFFll) return LVA_ERR_ARG;
+    const int64_t nb = len[i];
+    if (nb < 0 || nb > 0xFFFFFFFFll || beg[i] < 0) return LVA_ERR_ARG;
     if ((uint64_t)nb < (uint64_t)npos + 1) out_counts[i] = LVA_ERR_POST_TOO_SHORT;
     else { out_counts[i] = 0; order.push_back(i); }
   }
   // longest first: the tail of the schedule is then made of short reads
-  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return off[a + 1] - off[a] > off[b + 1] - off[b]; });
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return len[a] > len[b]; });
 
   if ((size_t)n > d->results_cap) {
     if (d->d_results) (void)hipFree(d->d_results);
@@ -336,7 +337,7 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* off
     for (size_t s = 0; s < slot.size(); ++s) {
       if (slot[s].read >= 0 || next >= order.size()) continue;
       const int32_t r = order[next++];
-      slot[s].read = r; slot[s].t = 0; slot[s].nblk = (uint32_t)(off[r + 1] - off[r]);
+      slot[s].read = r; slot[s].t = 0; slot[s].nblk = (uint32_t)len[r];
       slot[s].orient = rc_flags && rc_flags[r] ? 1u : 0u; slot[s].prev_hi = 1;
       const int e = launch_init_slot(g, d->d_codes, d->d_trellis, (uint32_t)s, slot[s].orient, d->stream);
       if (e) { g_hip_error = hipGetErrorString((hipError_t)e); return LVA_ERR_HIP; }
@@ -351,7 +352,7 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* off
       SlotStep& ss = a.s[a.nslots++];
       uint32_t lo, hi;
       d->code[slot[s].orient].band(slot[s].t, slot[s].nblk, d->max_dev, &lo, &hi);
-      ss.post_row = post_dev + ((size_t)off[slot[s].read] + slot[s].t) * 40;
+      ss.post_row = post_dev + ((size_t)beg[slot[s].read] + slot[s].t) * 40;
       ss.slot = (uint32_t)s; ss.t = slot[s].t; ss.lo = lo; ss.hi = hi; ss.prev_hi = slot[s].prev_hi;
       ss.orient = slot[s].orient;
       if (hi > lo) a.band_max = std::max(a.band_max, hi - lo);
@@ -412,7 +413,17 @@ int lva_decode_batch_device(lva_decoder* d, const float* post_dev, const int64_t
                             const uint8_t* rc_flags, uint8_t* out_msgs, float* out_scores, int32_t* out_counts) {
   if (!d || n_reads < 0 || !row_offsets || (n_reads > 0 && (!post_dev || !out_msgs || !out_counts))) return LVA_ERR_ARG;
   if (hipSetDevice(d->device) != hipSuccess) return LVA_ERR_NO_DEVICE;
-  return decode_impl(d, post_dev, row_offsets, n_reads, rc_flags, out_msgs, out_scores, out_counts, false);
+  std::vector<int64_t> len((size_t)n_reads);
+  for (int32_t i = 0; i < n_reads; ++i) len[i] = row_offsets[i + 1] - row_offsets[i];
+  return decode_impl(d, post_dev, row_offsets, len.data(), n_reads, rc_flags, out_msgs, out_scores, out_counts, false);
+}
+
+int lva_decode_windows_device(lva_decoder* d, const float* post_dev, const int64_t* first_block, const int64_t* n_blocks,
+                              int32_t n_reads, const uint8_t* rc_flags, uint8_t* out_msgs, float* out_scores,
+                              int32_t* out_counts) {
+  if (!d || n_reads < 0 || (n_reads > 0 && (!post_dev || !first_block || !n_blocks || !out_msgs || !out_counts))) return LVA_ERR_ARG;
+  if (hipSetDevice(d->device) != hipSuccess) return LVA_ERR_NO_DEVICE;
+  return decode_impl(d, post_dev, first_block, n_blocks, n_reads, rc_flags, out_msgs, out_scores, out_counts, false);
 }
 
 int lva_decode_batch(lva_decoder* d, const float* post, const int64_t* row_offsets, int32_t n_reads,
@@ -428,7 +439,9 @@ int lva_decode_batch(lva_decoder* d, const float* post, const int64_t* row_offse
   if (e == hipSuccess && blocks > 0)
     e = hipMemcpyAsync(dev, post, (size_t)blocks * 40 * sizeof(float), hipMemcpyHostToDevice, d->stream);
   if (e != hipSuccess) { g_hip_error = hipGetErrorString(e); (void)hipFree(dev); return LVA_ERR_HIP; }
-  const int st = decode_impl(d, dev, row_offsets, n_reads, rc_flags, out_msgs, out_scores, out_counts, true);
+  std::vector<int64_t> len((size_t)n_reads);
+  for (int32_t i = 0; i < n_reads; ++i) len[i] = row_offsets[i + 1] - row_offsets[i];
+  const int st = decode_impl(d, dev, row_offsets, len.data(), n_reads, rc_flags, out_msgs, out_scores, out_counts, true);
   (void)hipStreamSynchronize(d->stream);
   (void)hipFree(dev);
   return st;
@@ -459,6 +472,187 @@ int lva_device_upload(lva_decoder* d, void* dev_dst, const void* host_src, uint6
 int lva_device_synchronize(lva_decoder* d) {
   if (!d) return LVA_ERR_ARG;
   HIP_TRY(hipSetDevice(d->device));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  return LVA_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// basecall of the posterior matrix and barcode localisation.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct DevBlock {              // one device allocation carved into 256-byte aligned pieces
+  char* base = nullptr;
+  size_t used = 0, cap = 0;
+  ~DevBlock() { if (base) (void)hipFree(base); }
+  static size_t pad(size_t b) { return (b + 255) & ~(size_t)255; }
+  template <typename T> T* take(size_t count) {
+    T* p = reinterpret_cast<T*>(base + used);
+    used += pad(std::max<size_t>(count, 1) * sizeof(T));
+    return p;
+  }
+};
+
+bool rc_pattern(const char* src, int len, char* dst) {        // helper.reverse_complement (helper.py:227-229)
+  for (int i = 0; i < len; ++i) {
+    char c;
+    switch (src[len - 1 - i]) {
+      case 'A': c = 'T'; break;
+      case 'C': c = 'G'; break;
+      case 'G': c = 'C'; break;
+      case 'T': c = 'A'; break;
+      case 'N': c = 'N'; break;
+      default: return false;
+    }
+    dst[i] = c;
+  }
+  return true;
+}
+
+int make_patterns(const char* start_bc, const char* end_bc, int n_orient, BcPatterns* p) {
+  if (!start_bc || !end_bc) return LVA_ERR_ARG;
+  const size_t ls = std::strlen(start_bc), le = std::strlen(end_bc);
+  if (ls == 0 || le == 0 || ls > (size_t)kMaxBarcode || le > (size_t)kMaxBarcode) return LVA_ERR_ARG;
+  std::memset(p, 0, sizeof *p);
+  p->len[0] = (uint8_t)ls; p->len[1] = (uint8_t)le;
+  std::memcpy(p->pat[0], start_bc, ls);
+  std::memcpy(p->pat[1], end_bc, le);
+  if (n_orient == 2) {         // generate_decoded_lists.py:33-34: START_BARCODE_RC = rc(END), END_BARCODE_RC = rc(START)
+    p->len[2] = (uint8_t)le; p->len[3] = (uint8_t)ls;
+    if (!rc_pattern(end_bc, (int)le, p->pat[2]) || !rc_pattern(start_bc, (int)ls, p->pat[3])) return LVA_ERR_ARG;
+  }
+  return LVA_OK;
+}
+
+// basecall (and, when n_orient > 0, barcode localisation) of n reads whose posteriors are resident
+int bc_run(lva_decoder* d, const float* post_dev, const int64_t* row_offsets, int32_t n, const BcPatterns* pat,
+           int n_orient, uint32_t min_len, char* bases_out, uint32_t* trans_out, int32_t* nbases_out,
+           lva_payload_pos* pos_out) {
+  static_assert(sizeof(lva_payload_pos) == sizeof(BcResult), "lva_payload_pos layout");
+  if (n == 0) return LVA_OK;
+  for (int32_t i = 0; i < n; ++i)
+    if (row_offsets[i + 1] < row_offsets[i]) return LVA_ERR_ARG;
+  const size_t T = (size_t)(row_offsets[n] - row_offsets[0]);
+  if (row_offsets[0] != 0) return LVA_ERR_ARG;
+  DevBlock blk;
+  blk.cap = DevBlock::pad(8 * ((size_t)n + 1)) + DevBlock::pad(4 * T + 4) + DevBlock::pad(T + n + 1) + DevBlock::pad(T + 1) +
+            DevBlock::pad(4 * T + 4) + DevBlock::pad(4 * (size_t)n) + DevBlock::pad(16 * (size_t)n) + DevBlock::pad(24 * (size_t)n);
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&blk.base), blk.cap));
+  int64_t* d_off = blk.take<int64_t>((size_t)n + 1);
+  uint32_t* d_tb = blk.take<uint32_t>(T);
+  uint8_t* d_path = blk.take<uint8_t>(T + n);
+  char* d_bases = blk.take<char>(T);
+  uint32_t* d_trans = blk.take<uint32_t>(T);
+  int32_t* d_nb = blk.take<int32_t>(n);
+  uint32_t* d_best = blk.take<uint32_t>(4 * (size_t)n);
+  BcResult* d_res = blk.take<BcResult>(n);
+  HIP_TRY(hipMemcpyAsync(d_off, row_offsets, 8 * ((size_t)n + 1), hipMemcpyHostToDevice, d->stream));
+  int e = launch_bc_basecall(post_dev, d_off, n, d_tb, d_path, d_bases, d_trans, d_nb, d->stream);
+  if (!e && n_orient > 0) e = launch_bc_search(d_bases, d_off, d_nb, n, *pat, n_orient, d_best, d->stream);
+  if (!e && n_orient > 0) e = launch_bc_finalize(d_trans, d_off, d_nb, n, *pat, n_orient, min_len, d_best, d_res, d->stream);
+  if (e) { g_hip_error = hipGetErrorString((hipError_t)e); return LVA_ERR_HIP; }
+  if (bases_out && T) HIP_TRY(hipMemcpyAsync(bases_out, d_bases, T, hipMemcpyDeviceToHost, d->stream));
+  if (trans_out && T) HIP_TRY(hipMemcpyAsync(trans_out, d_trans, 4 * T, hipMemcpyDeviceToHost, d->stream));
+  if (nbases_out) HIP_TRY(hipMemcpyAsync(nbases_out, d_nb, 4 * (size_t)n, hipMemcpyDeviceToHost, d->stream));
+  if (pos_out && n_orient > 0) HIP_TRY(hipMemcpyAsync(pos_out, d_res, sizeof(BcResult) * (size_t)n, hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  return LVA_OK;
+}
+
+// host posteriors -> device copy for the duration of the call
+struct HostPost {
+  float* dev = nullptr;
+  ~HostPost() { if (dev) (void)hipFree(dev); }
+};
+
+int upload_post(lva_decoder* d, const float* post, const int64_t* row_offsets, int32_t n, HostPost* hp) {
+  const int64_t blocks = n > 0 ? row_offsets[n] : 0;
+  if (blocks < 0) return LVA_ERR_ARG;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&hp->dev), (size_t)std::max<int64_t>(blocks, 1) * 160));
+  if (blocks > 0) HIP_TRY(hipMemcpyAsync(hp->dev, post, (size_t)blocks * 160, hipMemcpyHostToDevice, d->stream));
+  return LVA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lva_basecall_batch_device(lva_decoder* d, const float* post_dev, const int64_t* row_offsets, int32_t n_reads,
+                              char* bases_out, uint32_t* trans_out, int32_t* nbases_out) {
+  if (!d || n_reads < 0 || !row_offsets || (n_reads > 0 && (!post_dev || !nbases_out))) return LVA_ERR_ARG;
+  if (hipSetDevice(d->device) != hipSuccess) return LVA_ERR_NO_DEVICE;
+  return bc_run(d, post_dev, row_offsets, n_reads, nullptr, 0, 0, bases_out, trans_out, nbases_out, nullptr);
+}
+
+int lva_basecall_batch(lva_decoder* d, const float* post, const int64_t* row_offsets, int32_t n_reads, char* bases_out,
+                       uint32_t* trans_out, int32_t* nbases_out) {
+  if (!d || n_reads < 0 || !row_offsets || (n_reads > 0 && (!post || !nbases_out))) return LVA_ERR_ARG;
+  if (hipSetDevice(d->device) != hipSuccess) return LVA_ERR_NO_DEVICE;
+  HostPost hp;
+  const int st = upload_post(d, post, row_offsets, n_reads, &hp);
+  if (st != LVA_OK) return st;
+  return bc_run(d, hp.dev, row_offsets, n_reads, nullptr, 0, 0, bases_out, trans_out, nbases_out, nullptr);
+}
+
+int lva_locate_payload_batch_device(lva_decoder* d, const float* post_dev, const int64_t* row_offsets, int32_t n_reads,
+                                    const char* start_barcode, const char* end_barcode, uint32_t min_len,
+                                    lva_payload_pos* out) {
+  if (!d || n_reads < 0 || !row_offsets || (n_reads > 0 && (!post_dev || !out))) return LVA_ERR_ARG;
+  if (hipSetDevice(d->device) != hipSuccess) return LVA_ERR_NO_DEVICE;
+  BcPatterns pat;
+  const int st = make_patterns(start_barcode, end_barcode, 2, &pat);
+  if (st != LVA_OK) return st;
+  return bc_run(d, post_dev, row_offsets, n_reads, &pat, 2, min_len, nullptr, nullptr, nullptr, out);
+}
+
+int lva_locate_payload_batch(lva_decoder* d, const float* post, const int64_t* row_offsets, int32_t n_reads,
+                             const char* start_barcode, const char* end_barcode, uint32_t min_len, lva_payload_pos* out) {
+  if (!d || n_reads < 0 || !row_offsets || (n_reads > 0 && (!post || !out))) return LVA_ERR_ARG;
+  if (hipSetDevice(d->device) != hipSuccess) return LVA_ERR_NO_DEVICE;
+  BcPatterns pat;
+  int st = make_patterns(start_barcode, end_barcode, 2, &pat);
+  if (st != LVA_OK) return st;
+  HostPost hp;
+  st = upload_post(d, post, row_offsets, n_reads, &hp);
+  if (st != LVA_OK) return st;
+  return bc_run(d, hp.dev, row_offsets, n_reads, &pat, 2, min_len, nullptr, nullptr, nullptr, out);
+}
+
+int lva_find_barcode_batch(lva_decoder* d, const char* bases, const uint32_t* trans, const int64_t* base_offsets,
+                           int32_t n_reads, const char* start_barcode, const char* end_barcode, lva_payload_pos* out) {
+  if (!d || n_reads < 0 || !base_offsets || (n_reads > 0 && (!bases || !trans || !out))) return LVA_ERR_ARG;
+  if (hipSetDevice(d->device) != hipSuccess) return LVA_ERR_NO_DEVICE;
+  if (n_reads == 0) return LVA_OK;
+  BcPatterns pat;
+  const int st = make_patterns(start_barcode, end_barcode, 1, &pat);
+  if (st != LVA_OK) return st;
+  if (base_offsets[0] != 0) return LVA_ERR_ARG;
+  std::vector<int32_t> nb(n_reads);
+  for (int32_t i = 0; i < n_reads; ++i) {
+    if (base_offsets[i + 1] < base_offsets[i]) return LVA_ERR_ARG;
+    nb[i] = (int32_t)(base_offsets[i + 1] - base_offsets[i]);
+  }
+  const size_t T = (size_t)base_offsets[n_reads], n = (size_t)n_reads;
+  DevBlock blk;
+  blk.cap = DevBlock::pad(8 * (n + 1)) + DevBlock::pad(T + 1) + DevBlock::pad(4 * T + 4) + DevBlock::pad(4 * n) +
+            DevBlock::pad(16 * n) + DevBlock::pad(24 * n);
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&blk.base), blk.cap));
+  int64_t* d_off = blk.take<int64_t>(n + 1);
+  char* d_bases = blk.take<char>(T);
+  uint32_t* d_trans = blk.take<uint32_t>(T);
+  int32_t* d_nb = blk.take<int32_t>(n);
+  uint32_t* d_best = blk.take<uint32_t>(4 * n);
+  BcResult* d_res = blk.take<BcResult>(n);
+  HIP_TRY(hipMemcpyAsync(d_off, base_offsets, 8 * (n + 1), hipMemcpyHostToDevice, d->stream));
+  if (T) HIP_TRY(hipMemcpyAsync(d_bases, bases, T, hipMemcpyHostToDevice, d->stream));
+  if (T) HIP_TRY(hipMemcpyAsync(d_trans, trans, 4 * T, hipMemcpyHostToDevice, d->stream));
+  HIP_TRY(hipMemcpyAsync(d_nb, nb.data(), 4 * n, hipMemcpyHostToDevice, d->stream));
+  int e = launch_bc_search(d_bases, d_off, d_nb, n_reads, pat, 1, d_best, d->stream);
+  if (!e) e = launch_bc_finalize(d_trans, d_off, d_nb, n_reads, pat, 1, 0, d_best, d_res, d->stream);
+  if (e) { g_hip_error = hipGetErrorString((hipError_t)e); return LVA_ERR_HIP; }
+  HIP_TRY(hipMemcpyAsync(out, d_res, sizeof(BcResult) * n, hipMemcpyDeviceToHost, d->stream));
   HIP_TRY(hipStreamSynchronize(d->stream));
   return LVA_OK;
 }

@@ -101,9 +101,9 @@ def algorithmic_bytes(mem_conv, rate, msg_len, nblk, list_size, max_deviation=No
 class Decoder:
     """A list-Viterbi decoder bound to one GPU.  Fails loudly without a GPU (no CPU path).
 
-    kernel: 0 = default (fast kernel + exact fix-up for list sizes 1, 2, 4, 8; the wavefront-per-target
-    exact kernel for other sizes up to 64; the thread-per-target exact kernel beyond), 1 = thread-per-target
-    exact kernel, 2 = fast kernel + fix-up, 3 = wavefront-per-target exact kernel.  All modes give the
+    kernel: 0 = default (fast kernels + exact fix-up for list sizes up to 64; the thread-per-target exact
+    kernel beyond), 1 = thread-per-target exact kernel, 2 = fast kernel + fix-up, 3 = wavefront-per-target
+    exact kernel.  All modes give the
     reference's lists bit for bit; they differ in speed only."""
 
     def __init__(self, mem_conv, rate, msg_len, list_size=1, max_deviation=None, sync_marker="", sync_period=0,
@@ -192,6 +192,105 @@ class Decoder:
         if st != 0:
             raise LvaError(st, self._L.lva_last_hip_error().decode())
         return self._unpack(n, msgs, scores, counts)
+
+    def _check(self, st):
+        if st != 0:
+            raise LvaError(st, self._L.lva_last_hip_error().decode())
+
+    def decode_windows_resident(self, dev_ptr, first_block, n_blocks, rc=None):
+        """decode windows [first_block[i], first_block[i] + n_blocks[i]) of a resident posterior buffer in place
+        (helper.truncate_post_file + the decode call of generate_decoded_lists.py:80-89, without the copy)"""
+        fb = np.ascontiguousarray(first_block, dtype=np.int64)
+        nb = np.ascontiguousarray(n_blocks, dtype=np.int64)
+        n = len(fb)
+        rcf = None if rc is None else np.ascontiguousarray(rc, dtype=np.uint8)
+        msgs, scores, counts = self._outputs(n)
+        self._check(self._L.lva_decode_windows_device(self._h, dev_ptr, fb.ctypes.data, nb.ctypes.data, n,
+                                                      None if rcf is None else rcf.ctypes.data,
+                                                      msgs.ctypes.data, scores.ctypes.data, counts.ctypes.data))
+        return self._unpack(n, msgs, scores, counts)
+
+    # --- SURVEY 8(f) row N3: basecall of the posterior matrix + barcode localisation ------------
+    def _basecall_out(self, off, bases, trans, nb):
+        return [(bases[off[i]:off[i] + nb[i]].tobytes().decode("ascii"), trans[off[i]:off[i] + nb[i]].astype(np.int64))
+                for i in range(len(nb))]
+
+    def basecall(self, posts):
+        """flappie's basecall of each posterior matrix (flappie.c:273-285): [(base string, trans positions)]"""
+        n = len(posts)
+        flat, off = self._pack(posts)
+        T = max(int(off[-1]), 1)
+        bases, trans, nb = np.zeros(T, np.uint8), np.zeros(T, np.uint32), np.zeros(max(n, 1), np.int32)
+        self._check(self._L.lva_basecall_batch(self._h, flat.ctypes.data, off.ctypes.data, n, bases.ctypes.data,
+                                               trans.ctypes.data, nb.ctypes.data))
+        return self._basecall_out(off, bases, trans, nb[:n])
+
+    def basecall_resident(self, dev_ptr, off):
+        n = len(off) - 1
+        T = max(int(off[-1]), 1)
+        bases, trans, nb = np.zeros(T, np.uint8), np.zeros(T, np.uint32), np.zeros(max(n, 1), np.int32)
+        self._check(self._L.lva_basecall_batch_device(self._h, dev_ptr, off.ctypes.data, n, bases.ctypes.data,
+                                                      trans.ctypes.data, nb.ctypes.data))
+        return self._basecall_out(off, bases, trans, nb[:n])
+
+    @staticmethod
+    def _payload_out(res, n):
+        inf = float("inf")
+        big = 0x7FFFFFFF
+        return [dict(ok=bool(r.ok), start_pos=r.start_pos, end_pos=r.end_pos, rc=bool(r.rc),
+                     dist_start=inf if r.dist_start == big else r.dist_start,
+                     dist_end=inf if r.dist_end == big else r.dist_end) for r in res[:n]]
+
+    def find_barcode(self, basecalls, trans_lists, start_barcode, end_barcode):
+        """helper.find_barcode_pos_in_post (helper.py:157-210) for a batch of (basecall, trans list) pairs"""
+        n = len(basecalls)
+        off = np.zeros(n + 1, np.int64)
+        off[1:] = np.cumsum([len(b) for b in basecalls])
+        for b, t in zip(basecalls, trans_lists):
+            if len(t) < len(b):
+                raise ValueError("trans list shorter than the basecall")
+        bases = np.frombuffer("".join(basecalls).encode("ascii") or b"\0", dtype=np.uint8).copy()
+        trans = np.concatenate([np.asarray(t, dtype=np.uint32)[:len(b)] for b, t in zip(basecalls, trans_lists)]
+                               + [np.zeros(1, np.uint32)])
+        res = (_lib.PayloadPos * max(n, 1))()
+        self._check(self._L.lva_find_barcode_batch(self._h, bases.ctypes.data, trans.ctypes.data, off.ctypes.data, n,
+                                                   start_barcode.encode(), end_barcode.encode(), res))
+        return self._payload_out(res, n)
+
+    def locate_payload(self, posts, start_barcode, end_barcode):
+        """generate_decoded_lists.py:68-79 per read: basecall, barcode search in both orientations, choice.
+        -> [dict(ok, start_pos, end_pos, rc, dist_start, dist_end)]"""
+        n = len(posts)
+        flat, off = self._pack(posts)
+        res = (_lib.PayloadPos * max(n, 1))()
+        self._check(self._L.lva_locate_payload_batch(self._h, flat.ctypes.data, off.ctypes.data, n, start_barcode.encode(),
+                                                     end_barcode.encode(), self.mem_conv + self.msg_len + 1, res))
+        return self._payload_out(res, n)
+
+    def locate_payload_resident(self, dev_ptr, off, start_barcode, end_barcode):
+        n = len(off) - 1
+        res = (_lib.PayloadPos * max(n, 1))()
+        self._check(self._L.lva_locate_payload_batch_device(self._h, dev_ptr, off.ctypes.data, n, start_barcode.encode(),
+                                                            end_barcode.encode(), self.mem_conv + self.msg_len + 1, res))
+        return self._payload_out(res, n)
+
+    def decode_with_barcodes(self, posts, start_barcode, end_barcode):
+        """The real-data chain of generate_decoded_lists.py:68-89 on the device: posteriors are uploaded once,
+        payload windows located, then decoded in place.  -> [(locate dict, decode result or None)]"""
+        n = len(posts)
+        dev, off = self.upload(posts)
+        try:
+            loc = self.locate_payload_resident(dev, off, start_barcode, end_barcode)
+            good = [i for i in range(n) if loc[i]["ok"]]
+            dec = self.decode_windows_resident(dev, [off[i] + loc[i]["start_pos"] for i in good],
+                                               [loc[i]["end_pos"] - loc[i]["start_pos"] + 1 for i in good],
+                                               rc=[loc[i]["rc"] for i in good]) if good else []
+        finally:
+            self.free(dev)
+        out = [(loc[i], None) for i in range(n)]
+        for i, r in zip(good, dec):
+            out[i] = (loc[i], r)
+        return out
 
     def profile(self):
         p = _lib.Profile()

@@ -37,6 +37,41 @@ def read_seq(path):
         return f.readline().rstrip("\n")
 
 
+def find_barcode_pos(basecall, trans_arr, start_barcode, end_barcode):
+    """The search of find_barcode_pos_in_post (helper.py:173-210) on an in-memory basecall and list of
+    transition positions.  Host-side mirror of the device path (Decoder.find_barcode / locate_payload)."""
+    inf = float("inf")
+    n, ls, le = len(basecall), len(start_barcode), len(end_barcode)
+    if ls + le > n:
+        return (-1, -1, inf, inf)
+    sd = [levenshtein(start_barcode, basecall[i:i + ls]) for i in range(n // 2 + 1 - ls)]
+    ed = [levenshtein(end_barcode, basecall[i:i + le]) for i in range(n // 2, n - le)]
+    if not sd or not ed:        # the reference raises here (min of an empty list)
+        return (-1, -1, inf, inf)
+    s_first = sd.index(min(sd))
+    e_first = n // 2 + ed.index(min(ed))
+    start_pos = int(trans_arr[s_first + ls]) - 1
+    end_pos = int(trans_arr[e_first - 1]) - 1
+    if end_pos < start_pos:
+        return (-1, -1, inf, inf)
+    return (start_pos, end_pos, min(sd), min(ed))
+
+
+def find_barcode_pos_in_post(trans_filename, fastq_filename, start_barcode, end_barcode, decoder=None):
+    """helper.py:157-210: position of the payload in the posterior matrix from flappie's fastq (second line =
+    basecall) and --trans-output-file.  -> (start_pos, end_pos, start distance, end distance), both positions
+    inclusive; (-1, -1, inf, inf) on failure.  With `decoder` (a Decoder) the search runs on its GPU."""
+    with open(fastq_filename) as f:
+        f.readline()
+        basecall = f.readline().rstrip("\n")
+    with open(trans_filename) as f:
+        trans_arr = [int(x) for x in f.read().split()]
+    if decoder is None:
+        return find_barcode_pos(basecall, trans_arr, start_barcode, end_barcode)
+    r = decoder.find_barcode([basecall], [trans_arr], start_barcode, end_barcode)[0]
+    return (r["start_pos"], r["end_pos"], r["dist_start"], r["dist_end"])
+
+
 def truncate_post(post, start_pos, end_pos):
     """rows [start_pos, end_pos] (inclusive) of a [nblk, 40] posterior matrix"""
     post = np.asarray(post, dtype=np.float32).reshape(-1, 40)

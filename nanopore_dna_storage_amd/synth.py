@@ -104,6 +104,32 @@ def make_read(mem_conv, rate, msg_len, seed, rc=False, margin=6.0, sub=0.0, dele
     return dict(msg=msg, oligo=oligo, read_bases=seq, post=post, rc=bool(rc), seed=seed)
 
 
+BASES = "ACGT"
+
+
+def bases_from_str(s):
+    return np.array([BASES.index(c) for c in s], dtype=np.uint8)
+
+
+def make_barcoded_read(mem_conv, rate, msg_len, seed, start_barcode, end_barcode, rc=False, margin=6.0,
+                       flank=(10, 40), sub=0.0, dele=0.0, ins=0.0):
+    """A read as the sequencer sees it in the reference's experiments (generate_decoded_lists.py:56-84):
+    random flank + start barcode + oligo + end barcode + random flank, optionally the reverse-complement
+    strand, with the untruncated posterior matrix.  -> dict(msg, oligo, strand, post, rc)"""
+    rng = np.random.default_rng(seed)
+    msg = rng.integers(0, 2, size=msg_len, dtype=np.uint8)
+    oligo = encode(mem_conv, rate, msg_len, msg)
+    f5 = rng.integers(0, 4, size=int(rng.integers(flank[0], flank[1] + 1)), dtype=np.uint8)
+    f3 = rng.integers(0, 4, size=int(rng.integers(flank[0], flank[1] + 1)), dtype=np.uint8)
+    strand = np.concatenate([f5, bases_from_str(start_barcode), oligo, bases_from_str(end_barcode), f3]).astype(np.uint8)
+    if rc:
+        strand = reverse_complement_bases(strand)
+    if sub or dele or ins:
+        strand = mutate(strand, rng, sub, dele, ins)
+    post = posteriors_from_bases(strand, rng, margin=margin)
+    return dict(msg=msg, oligo=oligo, strand=strand, post=post, rc=bool(rc), seed=seed)
+
+
 def make_reads(mem_conv, rate, msg_len, n, seed0=0, rc_mode="none", margin=6.0, **kw):
     """rc_mode: 'none', 'all', or 'odd' (odd-numbered reads are reverse complements)."""
     code_info(mem_conv, rate, msg_len)    # validates the parameters

@@ -49,6 +49,9 @@ def lib():
                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
         L.lva_oracle_band.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                       ctypes.c_int, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+        L.bc_oracle_basecall.restype = ctypes.c_int
+        L.bc_oracle_basecall.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
         _lib = L
     return _lib
 
@@ -173,3 +176,76 @@ def ref_decode(mem_conv, rate, msg_len, post, list_size, max_deviation=None, rc=
             return r.returncode, []
         with open(fout) as f:
             return 0, [ln.rstrip("\n") for ln in f]
+
+
+# ---------------------------------------------------------------------------------------------
+# flappie basecall of the .post matrix + barcode localisation.
+# PARITY UNPINNED for the basecall (see oracle/basecall_oracle.c); the barcode search restates
+# helper.py / generate_decoded_lists.py, which cannot be imported here (h5py, distance, scrappy
+# are absent) -- checked against brute force and hand-made cases only.
+# ---------------------------------------------------------------------------------------------
+def basecall(post):
+    """flappie.c:273-285 on a float32[nblk][40] posterior matrix -> (basecall str, trans positions
+    (the --trans-output-file lines), state path of nblk+1 entries, Viterbi score)."""
+    post = np.ascontiguousarray(post, dtype=np.float32).reshape(-1, 40)
+    nblk = post.shape[0]
+    path = np.zeros(nblk + 1, dtype=np.int32)
+    bases = np.zeros(max(nblk, 1), dtype=np.uint8)
+    trans = np.zeros(max(nblk, 1), dtype=np.uint32)
+    score = ctypes.c_float(0.0)
+    n = lib().bc_oracle_basecall(post.ctypes.data, nblk, path.ctypes.data, bases.ctypes.data, trans.ctypes.data,
+                                 ctypes.byref(score))
+    if n < 0:
+        raise OracleError(n)
+    return bases[:n].tobytes().decode("ascii"), trans[:n].astype(np.int64), path, float(score.value)
+
+
+def levenshtein(a, b):
+    """distance.levenshtein (the `distance` package used by helper.py:5,183,187): unit-cost edit distance."""
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i] + [0] * len(b)
+        for j, cb in enumerate(b, 1):
+            cur[j] = min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb))
+        prev = cur
+    return prev[len(b)]
+
+
+def find_barcode_pos(basecall_str, trans_arr, start_barcode, end_barcode):
+    """helper.find_barcode_pos_in_post (helper.py:157-210) on an in-memory basecall and trans list.
+    Returns (start_pos, end_pos, min start distance, min end distance); (-1, -1, inf, inf) on failure.
+    Where the reference would raise (an empty search range, helper.py:190-191 min() of an empty
+    list) this returns the failure tuple too."""
+    inf = float("inf")
+    n, ls, le = len(basecall_str), len(start_barcode), len(end_barcode)
+    if ls + le > n:                                                       # :177-179
+        return (-1, -1, inf, inf)
+    sd = [levenshtein(start_barcode, basecall_str[i:i + ls]) for i in range(n // 2 + 1 - ls)]       # :181-183
+    ed = [levenshtein(end_barcode, basecall_str[i:i + le]) for i in range(n // 2, n - le)]          # :185-187
+    if not sd or not ed:
+        return (-1, -1, inf, inf)
+    s_first = sd.index(min(sd))                                           # :190
+    e_first = n // 2 + ed.index(min(ed))                                  # :191
+    s_last = s_first + ls - 1
+    start_pos = int(trans_arr[s_last + 1]) - 1                            # :193
+    end_pos = int(trans_arr[e_first - 1]) - 1                             # :194
+    if end_pos < start_pos:                                               # :206-208
+        return (-1, -1, inf, inf)
+    return (start_pos, end_pos, min(sd), min(ed))
+
+
+def reverse_complement(dna):
+    return "".join({"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}[c] for c in dna[::-1])   # helper.py:227-229
+
+
+def locate_payload(post, start_barcode, end_barcode, min_len):
+    """generate_decoded_lists.py:68-84 for one read: both orientations, the smaller barcode
+    distance sum wins (forward on a draw); returns dict(ok, start_pos, end_pos, rc, dist_start, dist_end).
+    min_len = MEM_CONV + MSG_LEN + 1 (:76)."""
+    bc, trans, _, _ = basecall(post)
+    f = find_barcode_pos(bc, trans, start_barcode, end_barcode)
+    r = find_barcode_pos(bc, trans, reverse_complement(end_barcode), reverse_complement(start_barcode))   # :33-34, :69
+    rc = f[2] + f[3] > r[2] + r[3]                                        # :71
+    sp, ep, ds, de = r if rc else f
+    ok = not (sp == -1 or ep - sp + 1 < min_len)                          # :76
+    return dict(ok=ok, start_pos=sp, end_pos=ep, rc=bool(rc), dist_start=ds, dist_end=de, basecall=bc, trans=trans)
