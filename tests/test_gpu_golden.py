@@ -105,6 +105,35 @@ def test_generate_decoded_lists(tmp_path):
         assert lines[0] == "".join(map(str, reads[i]["msg"]))
 
 
+def test_generate_decoded_lists_from_untruncated_posts(tmp_path):
+    """3-column manifest rows: basecall + barcode search + decode on the device (generate_decoded_lists.py:68-89)"""
+    sb, eb = "CACCTGTGCTGCGTCAGGCTGTGTC", "GCTGTCCGTTCCGCATTGACACGGC"
+    reads = [synth.make_barcoded_read(6, 1, 60, 90 + i, sb, eb, rc=bool(i & 1), margin=6.0, flank=(5, 14)) for i in range(3)]
+    rows = []
+    for i, rd in enumerate(reads):
+        p = tmp_path / ("f%d.post" % i)
+        rd["post"].tofile(p)
+        rows.append("read%d\tref%d\t%s" % (i, i, p))
+    junk = tmp_path / "junk.post"
+    np.random.default_rng(3).normal(0, 1, (400, 40)).astype(np.float32).tofile(junk)     # no barcodes in there
+    rows.append("read3\tref3\t%s" % junk)
+    man = tmp_path / "manifest.tsv"
+    man.write_text("\n".join(rows) + "\n")
+    args = generate_decoded_lists.build_parser().parse_args(
+        ["--post_manifest", str(man), "--out_prefix", str(tmp_path / "list"), "--info_file", str(tmp_path / "info.txt"),
+         "--mem_conv", "6", "--msg_len", "60", "--rate_conv", "1", "--list_size", "4",
+         "--start_barcode", sb, "--end_barcode", eb])
+    out = io.StringIO()
+    n = generate_decoded_lists.run(args, out=out)
+    assert n >= 3
+    for i in range(3):
+        lines = (tmp_path / ("list_%d" % i)).read_text().split()
+        assert lines[0] == "".join(map(str, reads[i]["msg"]))
+    # read1 is the reverse-complement strand; the junk read gets whatever window matches least badly, like the reference
+    assert out.getvalue().split("i: 1\n")[1].split("i: 2\n")[0].count("--rc") == 1
+    assert "--rc" not in out.getvalue().split("i: 1\n")[0]
+
+
 # ---- size-independent properties at the benchmark configuration (m=11, r=5/6, L=8, msg_len=180) ----
 
 @pytest.fixture(scope="module")
