@@ -133,6 +133,13 @@ def test_long_and_odd_lists_use_the_big_list_kernel(oracle, L):
     _compare(oracle, 8, 3, 44, L, 20, reads, kernel=3)
 
 
+@pytest.mark.parametrize("m,r,msg_len,L", [(8, 5, 180, 24), (8, 1, 240, 16), (6, 1, 150, 9)])
+def test_big_list_kernel_wide_messages(oracle, m, r, msg_len, L):
+    """3 and 4 message planes (lva_step_big<LL,3>, <LL,4>)"""
+    reads = [synth.make_read(m, r, msg_len, 1200 + i, rc=bool(i & 1), margin=3.0) for i in range(2)]
+    _compare(oracle, m, r, msg_len, L, 10, reads, kernel=2)
+
+
 @pytest.mark.parametrize("L", [5, 16, 64])
 def test_big_list_kernel_tie_stress(oracle, L):
     """quantised posteriors: equal scores everywhere, most targets go through the wavefront fix-up"""
