@@ -1171,18 +1171,22 @@ __device__ __forceinline__ int big_merge(const Geometry& g, const uint32_t* __re
   // outputs, entry l of the whole wavefront at a time (:771-774, :780-783, :799).  Every fingerprint
   // match filed under an entry must be the same message (else: collision, the exact path decides).
   bool good = true;
-  constexpr uint32_t GB = 4;       // entries whose loads are in flight together
+  constexpr uint32_t GB = LL >= 64 ? 6 : 4;       // entries whose loads are in flight together (VGPRs: the fingerprints are dead by now)
   for (uint32_t l0 = 0; l0 < L; l0 += GB) {
-    uint32_t m[GB][2 * P]; uint2 sh2[GB]; uint32_t iu[GB];
+    uint32_t m[GB][2 * P], q0[GB][2 * P]; uint2 sh2[GB]; uint32_t iu[GB], ir[GB];
 #pragma unroll
     for (uint32_t u = 0; u < GB; ++u) {
       const uint32_t l = l0 + u;
-      iu[u] = 0; sh2[u] = make_uint2(kNegInfBits, 0u);
+      iu[u] = 0; ir[u] = 0; sh2[u] = make_uint2(kNegInfBits, 0u);
       if (l < lc) {
         const uint32_t f = locate((uint32_t)s_acc[l * NT] | ((uint32_t)(acc_hi >> l) & 1u) << 8, &iu[u]);
         const uint32_t cv = iu[u] == 0 ? t.c : t.cp;
         sh2[u] = *reinterpret_cast<const uint2*>(prev + f + 2 * cv);
         load_msg<P>(prev + f + pw, N, cv, iu[u] == 0 ? t.np_dst : t.np_src, m[u]);
+        if ((rv0 >> l) & 1ull) {          // the first match filed under this entry: its load travels with the others
+          const uint32_t fr = locate((uint32_t)s_rej0[l * NT] | ((uint32_t)(rh0 >> l) & 1u) << 8, &ir[u]);
+          load_msg<P>(prev + fr + pw, N, ir[u] == 0 ? t.c : t.cp, ir[u] == 0 ? t.np_dst : t.np_src, q0[u]);
+        }
       }
     }
 #pragma unroll
@@ -1194,17 +1198,17 @@ __device__ __forceinline__ int big_merge(const Geometry& g, const uint32_t* __re
         push_bits<2 * P>(m[u], iu[u] == 0 ? 0u : t.sh, t.nb);
         store_msg<P>(cur + t.own + mul24(l, sBlk) + pw, N, t.c, t.np_dst, m[u]);
         if ((rv0 >> l) & 1ull) {
+          push_bits<2 * P>(q0[u], ir[u] == 0 ? 0u : t.sh, t.nb);
 #pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            if (((s2 ? rv1 : rv0) >> l) & 1ull) {
-              uint32_t ir;
-              const uint32_t fr = locate((uint32_t)(s2 ? s_rej1 : s_rej0)[l * NT] | ((uint32_t)((s2 ? rh1 : rh0) >> l) & 1u) << 8, &ir);
-              uint32_t qm[2 * P];
-              load_msg<P>(prev + fr + pw, N, ir == 0 ? t.c : t.cp, ir == 0 ? t.np_dst : t.np_src, qm);
-              push_bits<2 * P>(qm, ir == 0 ? 0u : t.sh, t.nb);
+          for (int w = 0; w < 2 * P; ++w) good &= (q0[u][w] == m[u][w]);
+          if ((rv1 >> l) & 1ull) {        // a second match on the same entry is rare: loaded here
+            uint32_t i1;
+            const uint32_t fr = locate((uint32_t)s_rej1[l * NT] | ((uint32_t)(rh1 >> l) & 1u) << 8, &i1);
+            uint32_t qm[2 * P];
+            load_msg<P>(prev + fr + pw, N, i1 == 0 ? t.c : t.cp, i1 == 0 ? t.np_dst : t.np_src, qm);
+            push_bits<2 * P>(qm, i1 == 0 ? 0u : t.sh, t.nb);
 #pragma unroll
-              for (int w = 0; w < 2 * P; ++w) good &= (qm[w] == m[u][w]);
-            }
+            for (int w = 0; w < 2 * P; ++w) good &= (qm[w] == m[u][w]);
           }
         }
       } else if (l < L) {
