@@ -135,3 +135,29 @@ def test_post_to_list_chain_on_device(oracle, dec):
         assert np.array_equal(res[0], wm) and np.array_equal(res[1].view(np.uint32), ws.view(np.uint32))
         assert np.array_equal(res[0][0], x["msg"])          # and the chain recovers the message
     assert n_ok >= 5
+
+
+def test_argument_errors_and_empty_batches(dec):
+    import ctypes
+    from nanopore_dna_storage_amd import _lib
+    L = _lib.load_library()
+    assert dec.basecall([]) == []
+    assert dec.locate_payload([], SB, EB) == []
+    assert dec.find_barcode([], [], SB, EB) == []
+    post = np.zeros((10, 40), np.float32)
+    bad_off = np.array([0, 7, 5], np.int64)                          # decreasing offsets
+    nb = np.zeros(2, np.int32)
+    assert L.lva_basecall_batch(dec._h, post.ctypes.data, bad_off.ctypes.data, 2, None, None, nb.ctypes.data) == -10
+    res = (_lib.PayloadPos * 2)()
+    assert L.lva_locate_payload_batch(dec._h, post.ctypes.data, bad_off.ctypes.data, 2, SB.encode(), EB.encode(), 10, res) == -10
+    assert L.lva_locate_payload_batch(dec._h, post.ctypes.data, None, 1, SB.encode(), EB.encode(), 10, res) == -10
+    with pytest.raises(pkg.LvaError):
+        dec.locate_payload([post], "ACGU", EB)                       # not a base the reverse complement knows
+    # windows: a negative first block is refused, a window shorter than the trellis is reported per read
+    dev, off = dec.upload([post])
+    try:
+        with pytest.raises(pkg.LvaError):
+            dec.decode_windows_resident(dev, [-1], [10])
+        assert dec.decode_windows_resident(dev, [0], [10]) == [-6]
+    finally:
+        dec.free(dev)
