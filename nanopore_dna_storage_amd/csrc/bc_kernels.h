@@ -18,7 +18,7 @@ struct BcResult {          // layout of lva_payload_pos (include/lva_decoder.h)
   int32_t start_pos, end_pos, dist_start, dist_end, rc, ok;
 };
 
-// one thread per read: Viterbi forward pass, traceback, base / transition-position list
+// 8 lanes per read: Viterbi forward pass, traceback, base / transition-position list.  tb: 8 bytes per block
 int launch_bc_basecall(const float* post, const int64_t* row_off, int32_t n_reads, uint32_t* tb, uint8_t* path,
                        char* bases, uint32_t* trans, int32_t* nbases, void* stream);
 // best edit-distance match of every pattern; n_orient = 1 (patterns 0,1) or 2 (all four)

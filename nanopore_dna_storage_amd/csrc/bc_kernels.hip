@@ -4,8 +4,7 @@
 //                 combine_stays = false as flappie.c:273 calls it), change_positions (decode.c:66-79)
 //                 and the base / position lists flappie writes to the fastq and --trans-output-file
 //                 (flappie.c:274-285).  An 8-state recurrence with a dependent chain of nblk steps:
-//                 one thread per read, scores in registers, the 8 back-pointers of a block packed into
-//                 one 32-bit word.
+//                 8 lanes per read (one per state), 8 reads per wavefront.
 //   bc_search     helper.find_barcode_pos_in_post's search loops (helper.py:181-191): unit-cost edit
 //                 distance of the barcode against every window of the basecall in the allowed half, one
 //                 thread per window, first minimum wins.
@@ -18,73 +17,125 @@
 
 namespace lva {
 
+// One wavefront = 8 reads x 8 lanes; lane s of a group owns crf state s of its read (0-3 flip, 4-7 flop).
+// Per block the 8 scores of a read are exchanged inside the group (ds_bpermute), lane s adds the
+// transition weights into its state in flappie's candidate order and keeps the first maximum; its
+// back-pointer goes to byte s of the block's 8-byte traceback row.  The posterior rows of the next four
+// blocks are in flight while the current four are consumed.
 __global__ __launch_bounds__(64) void bc_basecall(const float* __restrict__ post, const int64_t* __restrict__ row_off,
-                                                  int32_t n_reads, uint32_t* __restrict__ tb, uint8_t* __restrict__ path,
+                                                  int32_t n_reads, uint8_t* __restrict__ tb, uint8_t* __restrict__ path,
                                                   char* __restrict__ bases, uint32_t* __restrict__ trans,
                                                   int32_t* __restrict__ nbases) {
-  const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n_reads) return;
-  const int64_t off = row_off[r];
-  const uint32_t nblk = (uint32_t)(row_off[r + 1] - off);
-  const float4* p = reinterpret_cast<const float4*>(post + off * 40);
-  uint32_t* tbr = tb + off;
-  uint8_t* pr = path + off + r;              // nblk + 1 states per read
-  float prev[8], curr[8];
-#pragma unroll
-  for (int s = 0; s < 8; ++s) prev[s] = 0.0f;                            // calloc (:131)
-  for (uint32_t blk = 0; blk < nblk; ++blk) {                             // forwards pass (:145-183)
-    float t[40];
-#pragma unroll
-    for (int q = 0; q < 10; ++q) {
-      const float4 v = p[(size_t)blk * 10 + q];
-      t[4 * q] = v.x; t[4 * q + 1] = v.y; t[4 * q + 2] = v.z; t[4 * q + 3] = v.w;
+  const uint32_t lane = threadIdx.x, s = lane & 7u, grp = lane & ~7u;
+  const int32_t r = blockIdx.x * 8 + (int32_t)(lane >> 3);
+  const bool live = r < n_reads;
+  const int64_t off = live ? row_off[r] : 0;
+  const uint32_t nblk = live ? (uint32_t)(row_off[r + 1] - off) : 0u;
+  const float* p = post + off * 40;
+  uint8_t* tbr = tb + off * 8;               // 8 back-pointers per block
+  uint8_t* pr = path + off + (live ? r : 0); // nblk + 1 states per read
+  // what lane s reads of a block: a flip state the 8 weights into it (32 contiguous bytes), a flop state
+  // the weights of "stay in flop" and "flip -> flop" (decode.c:157-165)
+  const bool flip = s < 4;
+  auto load_block = [&](uint32_t blk, float (&t)[8]) {
+    const float* q = p + (size_t)blk * 40;
+    if (flip) {
+      const float4 a = *reinterpret_cast<const float4*>(q + s * 8), b = *reinterpret_cast<const float4*>(q + s * 8 + 4);
+      t[0] = a.x; t[1] = a.y; t[2] = a.z; t[3] = a.w; t[4] = b.x; t[5] = b.y; t[6] = b.z; t[7] = b.w;
+    } else {
+      t[0] = q[32 + s]; t[1] = q[32 + s - 4];
     }
-    uint32_t back = 0;
+  };
+  float mine = 0.0f;                                                      // calloc (:131)
+  constexpr uint32_t D = 4;                  // blocks per chunk: the next chunk's rows are in flight while this one is consumed
+  float tn[D][8];
 #pragma unroll
-    for (int b2 = 4; b2 < 8; ++b2) {
-      float best = prev[b2] + t[32 + b2];                                 // stay in flop (:157-158)
-      uint32_t from = b2;
-      const float score = prev[b2 - 4] + t[32 + b2 - 4];                  // flip -> flop (:160-165)
-      if (score > best) { best = score; from = b2 - 4; }
-      curr[b2] = best; back |= from << (3 * b2);
+  for (uint32_t u = 0; u < D; ++u) {
+#pragma unroll
+    for (int f = 0; f < 8; ++f) tn[u][f] = 0.0f;
+    if (u < nblk) load_block(u, tn[u]);
+  }
+  for (uint32_t blk0 = 0; __any(blk0 < nblk); blk0 += D) {                // forwards pass (:145-183)
+    float tc[D][8];
+#pragma unroll
+    for (uint32_t u = 0; u < D; ++u) {
+#pragma unroll
+      for (int f = 0; f < 8; ++f) tc[u][f] = tn[u][f];
+      if (blk0 + D + u < nblk) load_block(blk0 + D + u, tn[u]);
     }
 #pragma unroll
-    for (int b1 = 0; b1 < 4; ++b1) {                                      // flip states (:169-182)
-      float best = t[b1 * 8] + prev[0];
-      uint32_t from = 0;
+    for (uint32_t u = 0; u < D; ++u) {
+      const uint32_t blk = blk0 + u;
+      const bool on = blk < nblk;
+      float pv[8];
 #pragma unroll
-      for (int f = 1; f < 8; ++f) {
-        const float score = t[b1 * 8 + f] + prev[f];
-        if (score > best) { best = score; from = f; }
+      for (int f = 0; f < 8; ++f) pv[f] = __shfl(mine, (int)(grp | (uint32_t)f));
+      float best; uint32_t from;
+      if (flip) {                                                         // flip states (:169-182)
+        best = tc[u][0] + pv[0]; from = 0;
+#pragma unroll
+        for (int f = 1; f < 8; ++f) {
+          const float score = tc[u][f] + pv[f];
+          if (score > best) { best = score; from = f; }
+        }
+      } else {
+        float own = pv[4], below = pv[0];                                 // prev[b2], prev[b2 - nbase]
+#pragma unroll
+        for (int f = 1; f < 4; ++f) { own = s == 4u + f ? pv[4 + f] : own; below = s == 4u + f ? pv[f] : below; }
+        best = own + tc[u][0]; from = s;                                  // stay in flop (:157-158)
+        const float score = below + tc[u][1];                             // flip -> flop (:160-165)
+        if (score > best) { best = score; from = s - 4; }
       }
-      curr[b1] = best; back |= from << (3 * b1);
+      if (on) { mine = best; tbr[(size_t)blk * 8 + s] = (uint8_t)from; }
     }
-    tbr[blk] = back;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) prev[s] = curr[s];
   }
-  uint32_t st = 0;                                                        // argmaxf: first maximum (util.c:17-31)
-  float vmax = prev[0];
+  // argmaxf: first maximum (util.c:17-31)
+  float pv[8];
 #pragma unroll
-  for (int s = 1; s < 8; ++s) if (prev[s] > vmax) { vmax = prev[s]; st = s; }
-  if (nblk == 0) { nbases[r] = 0; pr[0] = (uint8_t)st; return; }
-  pr[nblk] = (uint8_t)st;                                                 // traceback (:186-193)
-  for (uint32_t blk = nblk; blk > 0; --blk) {
-    st = (tbr[blk - 1] >> (3 * st)) & 7u;
-    pr[blk - 1] = (uint8_t)st;
-  }
-  int32_t nch = 0;                                                        // change_positions(path, nblock, ..) + flappie.c:276-285
-  uint32_t last = pr[0];
-  for (uint32_t pos = 1; pos < nblk; ++pos) {
-    const uint32_t s = pr[pos];
-    if (s != last) {
-      trans[off + nch] = pos;
-      bases[off + nch] = "ACGT"[s & 3u];
-      ++nch;
+  for (int f = 0; f < 8; ++f) pv[f] = __shfl(mine, (int)(grp | (uint32_t)f));
+  uint32_t st = 0;
+  float vmax = pv[0];
+#pragma unroll
+  for (int f = 1; f < 8; ++f) if (pv[f] > vmax) { vmax = pv[f]; st = f; }
+  __threadfence_block();
+  __syncthreads();                                                        // traceback rows written by the other lanes
+  // traceback (:186-193): every lane of the group walks the same chain, lane 0 records it
+  if (live && s == 0) pr[nblk] = (uint8_t)st;
+  for (uint32_t top = nblk; top > 0;) {                                   // 8 rows in flight, then 8 dependent look-ups
+    const uint32_t cnt = top < 8u ? top : 8u;
+    uint2 rows[8];
+#pragma unroll
+    for (uint32_t u = 0; u < 8; ++u)
+      rows[u] = u < cnt ? *reinterpret_cast<const uint2*>(tbr + (size_t)(top - 1 - u) * 8) : make_uint2(0u, 0u);
+    uint32_t packed = 0;                                                  // states of blocks top-1 .. top-8, 4 bits each
+#pragma unroll
+    for (uint32_t u = 0; u < 8; ++u) {
+      const uint32_t w = st < 4 ? rows[u].x : rows[u].y;
+      st = u < cnt ? (w >> (8 * (st & 3u))) & 7u : st;
+      packed |= st << (4 * u);
     }
-    last = s;
+    if (s < cnt) pr[top - 1 - s] = (uint8_t)((packed >> (4 * s)) & 7u);   // lane u of the group stores block top-1-u
+    top -= cnt;
   }
-  nbases[r] = nch;
+  __threadfence_block();
+  __syncthreads();                                                        // the path written by lane 0 of the group
+  // change_positions(path, nblock, ..) + flappie.c:276-285: 8 positions of a read at a time
+  const uint32_t gshift = lane & 56u;
+  uint32_t nch = 0;
+  for (uint32_t base = 1; __any(base < nblk); base += 8) {
+    const uint32_t pos = base + s;
+    uint32_t cur_s = 0;
+    bool flag = false;
+    if (pos < nblk) { cur_s = pr[pos]; flag = cur_s != pr[pos - 1]; }
+    const uint32_t m8 = (uint32_t)(__ballot(flag) >> gshift) & 0xFFu;
+    if (flag) {
+      const uint32_t idx = nch + __popc(m8 & ((1u << s) - 1u));
+      trans[off + idx] = pos;
+      bases[off + idx] = "ACGT"[cur_s & 3u];
+    }
+    nch += __popc(m8);
+  }
+  if (live && s == 0) nbases[r] = (int32_t)nch;
 }
 
 // grid: x = read, y = pattern (0 start, 1 end, 2 start-rc, 3 end-rc); 256 threads = 256 windows at a time
@@ -172,8 +223,8 @@ __global__ void bc_finalize(const uint32_t* __restrict__ trans, const int64_t* _
 int launch_bc_basecall(const float* post, const int64_t* row_off, int32_t n_reads, uint32_t* tb, uint8_t* path,
                        char* bases, uint32_t* trans, int32_t* nbases, void* stream) {
   if (n_reads <= 0) return 0;
-  hipLaunchKernelGGL(bc_basecall, dim3((n_reads + 63) / 64), dim3(64), 0, (hipStream_t)stream, post, row_off, n_reads, tb,
-                     path, bases, trans, nbases);
+  hipLaunchKernelGGL(bc_basecall, dim3((n_reads + 7) / 8), dim3(64), 0, (hipStream_t)stream, post, row_off, n_reads,
+                     reinterpret_cast<uint8_t*>(tb), path, bases, trans, nbases);
   return (int)hipGetLastError();
 }
 

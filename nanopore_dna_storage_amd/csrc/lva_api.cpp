@@ -537,11 +537,11 @@ int bc_run(lva_decoder* d, const float* post_dev, const int64_t* row_offsets, in
   const size_t T = (size_t)(row_offsets[n] - row_offsets[0]);
   if (row_offsets[0] != 0) return LVA_ERR_ARG;
   DevBlock blk;
-  blk.cap = DevBlock::pad(8 * ((size_t)n + 1)) + DevBlock::pad(4 * T + 4) + DevBlock::pad(T + n + 1) + DevBlock::pad(T + 1) +
+  blk.cap = DevBlock::pad(8 * ((size_t)n + 1)) + DevBlock::pad(8 * T + 8) + DevBlock::pad(T + n + 1) + DevBlock::pad(T + 1) +
             DevBlock::pad(4 * T + 4) + DevBlock::pad(4 * (size_t)n) + DevBlock::pad(16 * (size_t)n) + DevBlock::pad(24 * (size_t)n);
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&blk.base), blk.cap));
   int64_t* d_off = blk.take<int64_t>((size_t)n + 1);
-  uint32_t* d_tb = blk.take<uint32_t>(T);
+  uint32_t* d_tb = blk.take<uint32_t>(2 * T);          // 8 back-pointer bytes per block
   uint8_t* d_path = blk.take<uint8_t>(T + n);
   char* d_bases = blk.take<char>(T);
   uint32_t* d_trans = blk.take<uint32_t>(T);
