@@ -7,7 +7,7 @@
 //                 8 lanes per read (one per state), 8 reads per wavefront.
 //   bc_search     helper.find_barcode_pos_in_post's search loops (helper.py:181-191): unit-cost edit
 //                 distance of the barcode against every window of the basecall in the allowed half, one
-//                 thread per window, first minimum wins.
+//                 thread per window (bit-vector recurrence, 64-bit words), first minimum wins.
 //   bc_finalize   positions in the posterior matrix (helper.py:192-210), orientation choice and length
 //                 check of generate_decoded_lists.py:68-79.
 // Integer and fp32-add/compare work only: results are identical to the CPU restatement in oracle/.
@@ -138,17 +138,29 @@ __global__ __launch_bounds__(64) void bc_basecall(const float* __restrict__ post
   if (live && s == 0) nbases[r] = (int32_t)nch;
 }
 
-// grid: x = read, y = pattern (0 start, 1 end, 2 start-rc, 3 end-rc); 256 threads = 256 windows at a time
+// grid: x = read, y = pattern (0 start, 1 end, 2 start-rc, 3 end-rc); 256 threads = 256 windows at a time.
+// Edit distance of the barcode (m <= 64 characters) against a window: the bit-vector recurrence of Myers in
+// Hyyro's global-distance form -- column j of the DP matrix is kept as vertical +1 / -1 delta bit masks, the
+// horizontal delta entering row 0 is always +1 (D[0][j] = j), and the score follows bit m-1.  64-bit integer
+// arithmetic only: the value is the same D[m][m] the row-by-row DP of distance.levenshtein produces.
 __global__ __launch_bounds__(256) void bc_search(const char* __restrict__ bases, const int64_t* __restrict__ base_off,
                                                  const int32_t* __restrict__ nbases, BcPatterns pat,
                                                  uint32_t* __restrict__ best) {
-  __shared__ uint8_t rows[(kMaxBarcode + 1) * 256];      // DP row of thread t: rows[j * 256 + t]
+  __shared__ unsigned long long s_peq[4];        // bit i of s_peq[b]: pattern character i is base b
   __shared__ uint32_t red[4];
   const uint32_t r = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
   const int32_t n = nbases[r];
   const int32_t ls = pat.len[w & 2u], le = pat.len[(w & 2u) + 1];
   const int32_t m = pat.len[w];
   const char* txt = bases + base_off[r];
+  if (tid < 4) {
+    unsigned long long q = 0;
+    for (int32_t i = 0; i < m; ++i) q |= (unsigned long long)(pat.pat[w][i] == "ACGT"[tid]) << i;
+    s_peq[tid] = q;
+  }
+  __syncthreads();
+  const unsigned long long peq0 = s_peq[0], peq1 = s_peq[1], peq2 = s_peq[2], peq3 = s_peq[3];
+  const unsigned long long top = 1ull << (m - 1);
   uint32_t key = kBcNone;
   int32_t lo = 0, hi = 0;                                // windows [lo, hi)
   if (ls + le <= n) {                                    // helper.py:177-179
@@ -157,22 +169,22 @@ __global__ __launch_bounds__(256) void bc_search(const char* __restrict__ bases,
   }
   for (int32_t i = lo + (int32_t)tid; i < hi; i += 256) {
     // unit-cost edit distance of pat[w] and txt[i .. i+m)   (distance.levenshtein, helper.py:183,187)
-    for (int32_t j = 0; j <= m; ++j) rows[j * 256 + tid] = (uint8_t)j;
-    for (int32_t a = 1; a <= m; ++a) {
-      const char ca = pat.pat[w][a - 1];
-      uint32_t diag = rows[tid];                         // D[a-1][0]
-      rows[tid] = (uint8_t)a;
-      uint32_t left = a;
-      for (int32_t j = 1; j <= m; ++j) {
-        const uint32_t up = rows[j * 256 + tid];
-        const uint32_t sub = diag + (ca != txt[i + j - 1] ? 1u : 0u);
-        uint32_t v = up + 1 < left + 1 ? up + 1 : left + 1;
-        v = sub < v ? sub : v;
-        rows[j * 256 + tid] = (uint8_t)v;
-        diag = up; left = v;
-      }
+    unsigned long long vp = ~0ull, vn = 0ull;
+    uint32_t score = (uint32_t)m;
+    for (int32_t j = 0; j < m; ++j) {
+      const char ch = txt[i + j];
+      const unsigned long long eq = ch == 'A' ? peq0 : ch == 'C' ? peq1 : ch == 'G' ? peq2 : ch == 'T' ? peq3 : 0ull;
+      const unsigned long long x = eq | vn;
+      const unsigned long long d0 = ((vp + (x & vp)) ^ vp) | x;
+      const unsigned long long hn = vp & d0;
+      const unsigned long long hp = vn | ~(vp | d0);
+      score += (hp & top) ? 1u : 0u;
+      score -= (hn & top) ? 1u : 0u;
+      const unsigned long long xs = (hp << 1) | 1ull;
+      vn = xs & d0;
+      vp = (hn << 1) | ~(xs | d0);
     }
-    const uint32_t k = ((uint32_t)rows[m * 256 + tid] << 20) | (uint32_t)(i - lo);
+    const uint32_t k = (score << 20) | (uint32_t)(i - lo);
     key = k < key ? k : key;                             // smallest distance, then first index (:190-191)
   }
 #pragma unroll
