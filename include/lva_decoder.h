@@ -51,8 +51,9 @@ typedef struct lva_config {
   int32_t device;           /* HIP device ordinal */
   int32_t max_slots;        /* reads in flight on the device; 0 = choose from free HBM */
   int32_t kernel;           /* 0 = default (2 where available, else 3, else 1); 1 = exact kernel, one thread per
-                               target; 2 = fast kernel + exact fix-up (L = 1, 2, 4, 8); 3 = exact kernel, one
-                               wavefront per target (2 <= L <= 64) */
+                               target; 2 = fast kernel + exact fix-up (L = 1, 2, 4, 8: lva_step_fast; any other
+                               2 <= L <= 64: lva_step_big); 3 = exact kernel, one wavefront per target
+                               (2 <= L <= 64) */
   uint64_t mem_budget_bytes;/* cap on trellis memory; 0 = 60% of free HBM */
 } lva_config;
 
