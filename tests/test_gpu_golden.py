@@ -165,3 +165,39 @@ def test_full_size_properties(bench_reads):
     for i in range(6):
         assert np.array_equal(a[i][0][0], bench_reads[i]["msg"])
         assert np.array_equal(e[i][0][0], bench_reads[i]["msg"])
+
+
+def test_list_decode_with_crc_index_filter(oracle):
+    """configs[4] in small: index + payload + CRC-8 oligos (msg_len 164 = 12 + 8*18 + 8), m=8 rate 3/4, noisy reads,
+    list decoding + helper.decode_list_CRC_index / tallies (compute_error_rate_from_decoded_lists.py:18-56)"""
+    rng = np.random.default_rng(77)
+    num_oligos, bytes_per_oligo, L = 6, 18, 16
+    conv_in = [helper.attach_index_crc(i, rng.integers(0, 256, bytes_per_oligo, dtype=np.uint8).tobytes()) for i in range(num_oligos)]
+    assert all(len(x) == 164 for x in conv_in)
+    reads, truth = [], []
+    for i in range(10):
+        idx = int(rng.integers(num_oligos))
+        bits = np.frombuffer(conv_in[idx].encode(), dtype=np.uint8) - ord("0")
+        oligo = pkg.encode(8, 3, 164, bits)
+        rc = bool(i & 1)
+        seq = synth.reverse_complement_bases(oligo) if rc else oligo
+        post = synth.posteriors_from_bases(seq, rng, margin=4.0 if i % 3 else 5.0)     # rate 3/4 at m=8 needs margin > 3
+        reads.append((post, rc)); truth.append(idx)
+    with pkg.Decoder(8, 3, 164, list_size=L, max_deviation=20) as dec:
+        got = dec.decode([p for p, _ in reads], rc=[r for _, r in reads])
+    lists = [["".join(map(str, row)) for row in g[0]] for g in got]
+    want = []
+    for post, rc in reads:
+        wm, _ = oracle.OracleCode(8, 3, 164, rc=rc).decode(post, L, 20, num_threads=8)
+        want.append(["".join(map(str, row)) for row in wm])
+    assert lists == want
+    t = helper.tally_decoded_lists(lists, conv_in, bytes_per_oligo, False, L)
+    assert t == helper.tally_decoded_lists(want, conv_in, bytes_per_oligo, False, L)
+    assert t["num_reads"] == 10 and t["num_correct"] >= 5 and t["num_error_CRC_index"] <= 1
+    # the filter finds what the top-1 entry alone does not always give
+    top1 = helper.tally_decoded_lists(lists, conv_in, bytes_per_oligo, False, 1)
+    assert t["num_correct"] >= top1["num_correct"]
+    for lst, idx in zip(lists, truth):
+        i2, payload, msg = helper.decode_list_CRC_index(lst, bytes_per_oligo, num_oligos, False)
+        if i2 is not None and msg == conv_in[i2]:
+            assert i2 == idx
