@@ -1,25 +1,36 @@
 #!/usr/bin/env python3
-"""bench.py -- reads decoded/sec on the north-star configuration.
+"""bench.py -- reads decoded/sec on the north-star configuration (SURVEY.md section 8d).
 
-One "step" = one pass of the hot path (lva_decode_batch_device) over one batch of synthetic
-reads of BASELINE.json configs[1]'s shape: mem_conv=11, rate=5 (5/6), list_size=8,
-msg_len=180, max_deviation=20, forward and reverse-complement reads mixed.  The posteriors
-are already resident in HBM when the timed region starts.  With N GPUs each rank decodes its
-own shard of reads (reads are independent: no data-path collective; weak scaling) and the
-decoded lists are gathered on rank 0 after the timed region.
+Metric: reads decoded per second END TO END for the decode path -- host->device copy of the posterior
+matrices, every trellis step, final selection, device->host copy of the lists -- on BASELINE.json
+configs[1]'s shape: mem_conv=11, rate=5 (5/6), list_size=8, msg_len=180, max_deviation=20, forward and
+reverse-complement reads mixed.  It replaces the per-read loop of the reference's
+generate_decoded_lists.py:50-98 (one decoder subprocess per read).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      achieved algorithmic GB/s of the trellis-step kernel (SURVEY 8d bytes / HIP-event
-                kernel time, measured live on the decoder's stream) against the 8 TB/s HBM peak
-  cpu_baseline  the unmodified reference binary (oracle/_ref) timed on this host on a bounded sample
+One "step" = one call of the hot path's C-ABI entry lva_decode_batch on one batch of host-resident
+synthetic reads per GPU (--reads-per-step, default 4x the decoder's read slots, so slots are refilled
+inside the timed region); consecutive steps take consecutive batches out of a pool of --pool distinct
+reads per GPU (default 512).  `--resident` keeps the posteriors in HBM instead (lva_decode_batch_device).
+
+N GPUs: `python bench.py --gpus N` starts N rank processes itself (torch.distributed.run, one per GPU,
+before anything touches the GPU in the parent) unless it already runs as a rank (WORLD_SIZE set by the
+driver's launcher).  Reads are independent: every rank decodes its own shard with no data-path
+collective; the decoded lists are gathered on rank 0 through sharding.gather_results (RCCL) after the
+timed region.  Weak scaling by default (fixed reads per GPU); `--total-reads T` fixes the job instead
+(strong scaling, configs[2]'s shape: rank r takes reads r, r+N, ...).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+  roofline      algorithmic bytes (SURVEY 8d formula) / HIP-event time of the dominant kernel, measured live
+                on the decoder's stream around every launch, against the 8 TB/s HBM peak
+  cpu_baseline  the unmodified reference binary (oracle/_ref) on this host, all (<=16) OpenMP threads, on a
+                bounded sample of the same reads; cpu_baseline_single_thread: the same with -t 1
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -27,12 +38,15 @@ sys.path.insert(0, ROOT)
 M, RATE, MSG_LEN, LIST, MAXDEV = 11, 5, 180, 8, 20
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads-per-step", type=int, default=0, help="reads per GPU per step (0 = number of slots)")
+    ap.add_argument("--reads-per-step", type=int, default=0, help="reads per GPU per step (0 = 4 x read slots)")
+    ap.add_argument("--pool", type=int, default=512, help="distinct synthetic reads per GPU the steps cycle through")
+    ap.add_argument("--total-reads", type=int, default=0, help="strong scaling: reads per step over ALL GPUs")
+    ap.add_argument("--resident", action="store_true", help="posteriors resident in HBM before the timed region")
     ap.add_argument("--slots", type=int, default=0)
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--mem-conv", type=int, default=M)
@@ -42,143 +56,269 @@ def parse():
     ap.add_argument("--max-deviation", type=int, default=MAXDEV)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--check", type=int, default=1, help="(kept for compatibility; the parity check is part of the cpu_baseline leg)")
-    return ap.parse_args()
+    ap.add_argument("--cpu-reads", type=int, default=3, help="reads of the multi-thread reference sample")
+    ap.add_argument("--no-launch-events", action="store_true", help="no per-launch HIP events (roofline from the span)")
+    ap.add_argument("--dump-lists", type=str, default="", help="rank 0 writes the gathered lists of the last step (npz)")
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(a, post, rc=False):
-    """Reference decoder on this host, bounded sample: one read of the benchmark shape with all
-    (<=16) cores of OpenMP (its own -t flag).  Reported, never the target.  -> (baseline, list)"""
-    from oracle import oracle as O
-    cores = a.cpu_threads or min(os.cpu_count() or 1, 16)
-    nblk = post.shape[0]
-    if O.have_ref():
-        t0 = time.time()
-        rc_, lst = O.ref_decode(a.mem_conv, a.rate, a.msg_len, post, a.list_size, a.max_deviation, rc=rc, num_threads=cores)
-        dt = time.time() - t0
-        kind = "reference"
-        ok = rc_ == 0
-    else:
-        code = O.OracleCode(a.mem_conv, a.rate, a.msg_len, rc=rc)
-        t0 = time.time()
-        lst, _ = code.decode(post, a.list_size, a.max_deviation, num_threads=cores)
-        dt = time.time() - t0
-        kind = "port"
-        ok = True
-        lst = ["".join(map(str, x)) for x in lst]
-    return dict(value=(1.0 / dt) if ok else None, unit="reads/s", cores=cores, kind=kind,
-                sample="1 read (nblk=%d) of the benchmark shape, -t %d; wall %.1f s" % (nblk, cores, dt)), lst
+# ---------------------------------------------------------------------------------------------
+# CPU leg: the unmodified reference decoder (test infrastructure under oracle/), outside the timed region
+# ---------------------------------------------------------------------------------------------
+def _ref_cmd(O, a, post_path, out_path, rc, threads):
+    cmd = [O.REF_BIN, "-m", "decode", "-i", post_path, "-o", out_path, "--msg-len", str(a.msg_len), "--mem-conv",
+           str(a.mem_conv), "-r", str(a.rate), "-l", str(a.list_size), "-t", str(threads),
+           "--max-deviation", str(a.max_deviation)]
+    if rc:
+        cmd.append("--rc")
+    return cmd
+
+
+class RefJob:
+    """one reference decode as a child process (so that the single-thread sample can run beside the GPU leg)"""
+
+    def __init__(self, O, a, post, rc, threads, tmpdir):
+        self.post_path = os.path.join(tmpdir, "ref_%d_%d.post" % (threads, id(self)))
+        self.out_path = self.post_path + ".out"
+        post.tofile(self.post_path)
+        self.t0 = time.time()
+        self.p = subprocess.Popen(_ref_cmd(O, a, self.post_path, self.out_path, rc, threads), stdout=subprocess.DEVNULL)
+        self.wall = None
+
+    def wait(self, timeout=None):
+        rc_ = self.p.wait(timeout=timeout)
+        self.wall = time.time() - self.t0
+        lines = open(self.out_path).read().split("\n")[:-1] if (rc_ == 0 and os.path.exists(self.out_path)) else None
+        for f in (self.post_path, self.out_path):
+            if os.path.exists(f):
+                os.remove(f)
+        return rc_, lines
+
+
+def as_lines(res):
+    return ["".join("1" if b else "0" for b in row) for row in res[0]]
 
 
 def main():
     a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    backend = os.environ.get("LVA_BENCH_BACKEND", "nccl")    # "gloo": several ranks on one GPU (testing only)
-    ndev = 1
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        ndev = max(torch.cuda.device_count(), 1)
-        torch.cuda.set_device(local % ndev)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local % ndev))
-        else:
-            dist.init_process_group(backend)
-    coll_dev = "cuda" if backend == "nccl" else "cpu"
+    in_group = "WORLD_SIZE" in os.environ
+    # ---- self-launch: N ranks as fresh child processes; this parent never touches the GPU ----
+    if a.gpus > 1 and not in_group:
+        from nanopore_dna_storage_amd import sharding
+        sys.exit(sharding.launch_ranks(os.path.abspath(__file__), sys.argv[1:], a.gpus))
+    if os.environ.get("LVA_BENCH_SPAWN") == "1" and not in_group:        # tests: the spawn path with one rank
+        from nanopore_dna_storage_amd import sharding
+        sys.exit(sharding.launch_ranks(os.path.abspath(__file__), sys.argv[1:], a.gpus))
+
+    import numpy as np
+    from nanopore_dna_storage_amd import sharding
+    backend = os.environ.get("LVA_BENCH_BACKEND") or os.environ.get("LVA_DIST_BACKEND") or "nccl"
+    dist, rank, world, devno, coll_dev = sharding.init_rank(backend)
+    if in_group and world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (a.gpus, world))
 
     import nanopore_dna_storage_amd as pkg
     from nanopore_dna_storage_amd import synth
 
     dec = pkg.Decoder(a.mem_conv, a.rate, a.msg_len, list_size=a.list_size, max_deviation=a.max_deviation,
-                      device=local % ndev, max_slots=a.slots, kernel=a.kernel)
+                      device=devno, max_slots=a.slots, kernel=a.kernel)
     slots = dec.profile()["slots"]
-    per_rank = a.reads_per_step or slots
-    # deterministic synthetic shard of this rank: global read index = rank*per_rank + i
-    reads = [synth.make_read(a.mem_conv, a.rate, a.msg_len, seed=1000 + rank * per_rank + i,
-                             rc=bool((rank * per_rank + i) & 1), margin=6.0 if i % 4 else 3.0)
-             for i in range(per_rank)]
-    rc = [x["rc"] for x in reads]
-    dev_ptr, off = dec.upload([x["post"] for x in reads])      # inputs resident in HBM
+    if dist is not None and backend == "nccl":
+        import torch
+        devs = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
+        dist.all_gather(devs, torch.tensor([torch.cuda.current_device()], dtype=torch.int64, device="cuda"))
+        assert len({int(x.item()) for x in devs}) == world, "ranks share a GPU"
+
+    # ---- the reads of this rank ------------------------------------------------------------------
+    strong = a.total_reads > 0
+    if strong:
+        shards = sharding.shard_strided(a.total_reads, world)
+        mine = shards[rank]                       # global read indices of this rank, the same every step
+        per_step = len(mine)
+        pool_idx = [int(i) for i in mine]
+        nbatch = 1
+    else:
+        per_step = a.reads_per_step or 4 * slots
+        nbatch = max(1, -(-max(a.pool, 1) // per_step))     # batches in the pool
+        pool_idx = [rank * nbatch * per_step + i for i in range(nbatch * per_step)]
+        shards = [np.arange(r * per_step, (r + 1) * per_step, dtype=np.int64) for r in range(world)]
+
+    def make(gi):      # global read index -> read; every 5th read noisy (margin 3), odd reads reverse-complemented
+        return synth.make_read(a.mem_conv, a.rate, a.msg_len, seed=1000 + gi, rc=bool(gi & 1),
+                               margin=3.0 if gi % 5 == 0 else 6.0)
+
+    reads = [make(gi) for gi in pool_idx]
+    batches = []
+    for b in range(nbatch):
+        rs = reads[b * per_step:(b + 1) * per_step]
+        flat, off = pkg.Decoder.pack([x["post"] for x in rs])
+        batches.append(dict(flat=flat, off=off, rc=np.array([x["rc"] for x in rs], np.uint8), reads=rs))
+    if a.resident:
+        for bt in batches:
+            bt["dev"], _ = dec.upload([x["post"] for x in bt["reads"]])
+
+    # ---- CPU leg, part 1: the single-thread reference sample runs beside the GPU leg (its own core) ----
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        from oracle import oracle as O
+        import tempfile
+        cpu = dict(O=O, tmp=tempfile.mkdtemp(prefix="lva_bench_"))
+        if O.have_ref():
+            # read 5 of the pool: reverse complement, noisy (margin 3)
+            cpu["i1"] = 5 if len(batches[0]["reads"]) > 5 else 0
+            r1 = batches[0]["reads"][cpu["i1"]]
+            cpu["job1"] = RefJob(O, a, r1["post"], r1["rc"], 1, cpu["tmp"])
+
+    def run(bt):
+        if a.resident:
+            return dec.decode_resident(bt["dev"], bt["off"], bt["rc"])
+        return dec.decode_packed(bt["flat"], bt["off"], bt["rc"])
 
     def barrier():
         if dist is not None:
             import torch
-            torch.cuda.synchronize()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
             dist.barrier()
 
+    step_no = 0
+    outs = {}
     for _ in range(a.warmup):
-        out = dec.decode_resident(dev_ptr, off, rc)
+        outs[step_no % nbatch] = run(batches[step_no % nbatch]); step_no += 1
+    dec.set_launch_events(not a.no_launch_events)
     barrier()
-    kern_ms = alg_bytes = 0.0
-    launches = 0
-    fix = 0
+    acc = dict(span_ms=0.0, dom_ms=0.0, pair_ms=0.0, alg=0.0, launches=0, tl=0, read_steps=0, fix=0, h2d_ms=0.0, h2d_b=0,
+               total_ms=0.0)
     fixr = [0, 0, 0, 0]
-    sum_read_steps = 0
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        out = dec.decode_resident(dev_ptr, off, rc)    # returns after the stream is drained
+        b = step_no % nbatch
+        outs[b] = run(batches[b]); step_no += 1     # returns after the stream is drained and the lists are on the host
         p = dec.profile()
-        kern_ms += p["step_kernel_ms"]; alg_bytes += p["algorithmic_bytes"]; launches += p["step_launches"]
-        sum_read_steps += p["read_steps"]
-        fix += p["fixup_states"]; fixr = [x + y for x, y in zip(fixr, p["fixup_reason"])]
+        acc["span_ms"] += p["step_kernel_ms"]; acc["dom_ms"] += p["dominant_kernel_ms"]; acc["pair_ms"] += p["step_pair_ms"]
+        acc["alg"] += p["algorithmic_bytes"]; acc["launches"] += p["step_launches"]; acc["tl"] += p["timed_launches"]
+        acc["read_steps"] += p["read_steps"]; acc["fix"] += p["fixup_states"]
+        acc["h2d_ms"] += p["h2d_ms"]; acc["h2d_b"] += p["h2d_bytes"]; acc["total_ms"] += p["total_ms"]
+        fixr = [x + y for x, y in zip(fixr, p["fixup_reason"])]
     barrier()
     dt = time.perf_counter() - t0
+    last_b = (step_no - 1) % nbatch
+    gathered = None
     if dist is not None:
         import torch
-        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev or "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        # gather decoded top-1 lists on rank 0 (the path's only exchange step, ~230 B/read)
-        top = np.stack([o[0][0] if (not isinstance(o, int) and len(o[0])) else np.zeros(a.msg_len, np.uint8) for o in out])
-        tl = torch.from_numpy(top).to(coll_dev)
-        gl = [torch.empty_like(tl) for _ in range(world)] if rank == 0 else None
-        dist.gather(tl, gl, dst=0)
+    # the path's only exchange step: the decoded lists of the last step, gathered on rank 0 in global read order
+    gathered = sharding.gather_results(outs[last_b], shards, a.list_size, a.msg_len, dist=dist, device=coll_dev)
 
     if rank == 0:
-        total_reads = per_rank * world * a.steps
+        n_global = sum(len(s) for s in shards)
+        assert gathered is not None and len(gathered) == n_global and all(g is not None for g in gathered)
+        if a.dump_lists:
+            c, m_, s_ = sharding.pack_results(gathered, a.list_size, a.msg_len)
+            np.savez(a.dump_lists, counts=c, msgs=m_, scores=s_)
+        total_reads = n_global * a.steps
         nblk_mean = float(np.mean([x["post"].shape[0] for x in reads]))
+        distinct = min(len(pool_idx), per_step * (a.steps + a.warmup)) if not strong else per_step
+        prof = dec.profile()
         res = {
             "metric": "reads decoded/sec (m=%d, r=%d/%d, L=%d, msg_len=%d)" % (a.mem_conv, a.rate, a.rate + 1, a.list_size, a.msg_len),
             "value": total_reads / dt, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1e3 * dt / max(a.steps, 1), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * dt / max(a.steps, 1), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1] shape: mem_conv=%d rate=%d list_size=%d msg_len=%d max_deviation=%d, "
-                                   "%d reads per GPU per step (mean nblk %.0f), fwd/rc mixed, posteriors resident in HBM"
-                                   % (a.mem_conv, a.rate, a.list_size, a.msg_len, a.max_deviation, per_rank, nblk_mean),
-                       "reads_per_step_per_gpu": per_rank, "slots": slots, "kernel": dec.profile()["kernel"],
-                       "fixup_states": fix, "fixup_reason": fixr},
+            "config": {"workload": "configs[1] shape: mem_conv=%d rate=%d list_size=%d msg_len=%d max_deviation=%d; per step "
+                                   "%d reads per GPU (mean nblk %.0f, fwd/rc mixed, 1 in 5 noisy) through %s, %d read slots; "
+                                   "%d distinct reads per GPU"
+                                   % (a.mem_conv, a.rate, a.list_size, a.msg_len, a.max_deviation, per_step, nblk_mean,
+                                      "lva_decode_batch_device (posteriors resident in HBM)" if a.resident
+                                      else "lva_decode_batch (host buffers: H2D inside the timed region)", slots, distinct),
+                       "reads_per_step_per_gpu": per_step, "distinct_reads_per_gpu": distinct, "slots": slots,
+                       "h2d": "excluded (resident)" if a.resident else "included",
+                       "h2d_ms_per_step": acc["h2d_ms"] / max(a.steps, 1), "h2d_bytes_per_step": acc["h2d_b"] / max(a.steps, 1),
+                       "kernel": prof["kernel"], "fixup_states": acc["fix"], "fixup_reason": fixr,
+                       "gathered_lists": n_global},
         }
-        achieved = (alg_bytes / 1e9) / (kern_ms / 1e3) if kern_ms > 0 else 0.0
-        # HBM bytes per launch from the committed PMC profile (per read-step, scaled to this run's
-        # mean number of active slots per launch); only for the configuration that was profiled
-        traffic = None
+        use_events = acc["tl"] > 0
+        dom_ms = acc["dom_ms"] if use_events else acc["span_ms"]
+        achieved = (acc["alg"] / 1e9) / (dom_ms / 1e3) if dom_ms > 0 else 0.0
+        kname = {2: "lva_step_fast<%d,P>" % a.list_size if a.list_size in (1, 2, 4, 8) else "lva_step_big<LL,P>",
+                 3: "lva_step_wave", 1: "lva_step_exact"}.get(prof["kernel"], "?")
+        # HBM bytes per launch from this round's PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+        # passes, scripts/pmc_mem.sh), per read-step, scaled to this run's mean number of active slots per launch
+        traffic, tsrc = None, None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
-            if (a.mem_conv, a.rate, a.list_size, a.msg_len, a.max_deviation) == (11, 5, 8, 180, 20) and launches:
-                per_step = (tj["fetch_correction"] * tj["fetch_size_kb_per_launch"] + tj["write_size_kb_per_launch"]) * 1024.0 / tj["slots"]
-                traffic = per_step * (sum_read_steps / launches)
+            for name in ("r2_traffic.json", "r1_traffic.json"):
+                pth = os.path.join(ROOT, "profiles", name)
+                if os.path.exists(pth):
+                    tj = json.load(open(pth))
+                    if (a.mem_conv, a.rate, a.list_size, a.msg_len, a.max_deviation) == (11, 5, 8, 180, 20) and acc["launches"]:
+                        per_rs = (tj["fetch_correction"] * tj["fetch_size_kb_per_launch"] + tj["write_size_kb_per_launch"]) * 1024.0 / tj["slots"]
+                        traffic = per_rs * (acc["read_steps"] / acc["launches"])
+                        tsrc = "profiles/" + name + " (PMC run of an earlier invocation, scaled per read-step)"
+                    break
         except Exception:
             traffic = None
-        res["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                           "frac": achieved / 8000.0, "traffic": traffic,
-                           "kernel": "lva_step_fast + lva_step_fixup (one trellis step of every active slot)", "launches": launches,
-                           "avg_launch_ms": kern_ms / max(launches, 1),
-                           "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1)}
-        if world == 1 and not a.no_cpu_baseline:
-            # CPU leg (outside the timed region): the reference decoder on read 0 of this run --
-            # its wall time is the baseline, its output list is the parity check of the GPU result
-            cb, lst = cpu_baseline(a, reads[0]["post"], rc=rc[0])
-            got = ["".join("1" if b else "0" for b in row) for row in out[0][0]]
-            assert got == lst, "GPU result differs from the CPU reference on the benchmark read"
-            res["cpu_baseline"] = cb
-            res["config"]["reference_checked_reads"] = 1
-        print(json.dumps(res))
-    dec.free(dev_ptr)
+        res["roofline"] = {
+            "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+            "traffic": traffic, "traffic_source": tsrc,
+            "kernel": kname + " (one trellis step of every active read slot)",
+            "basis": ("algorithmic bytes / sum of per-launch HIP-event times of the dominant kernel alone" if use_events
+                      else "algorithmic bytes / HIP-event span first..last step launch"),
+            "launches": acc["launches"], "avg_launch_ms": dom_ms / max(acc["launches"], 1),
+            "algorithmic_bytes_per_launch": acc["alg"] / max(acc["launches"], 1),
+            "pair": {"kernel": kname + " + fix-up pass", "avg_launch_ms": acc["pair_ms"] / max(acc["tl"], 1),
+                     "achieved": (acc["alg"] / 1e9) / (acc["pair_ms"] / 1e3) if acc["pair_ms"] > 0 else None} if use_events else None,
+            "span": {"ms_per_launch": acc["span_ms"] / max(acc["launches"], 1),
+                     "achieved": (acc["alg"] / 1e9) / (acc["span_ms"] / 1e3) if acc["span_ms"] > 0 else None,
+                     "note": "first..last step launch incl. slot init / final gather launches"},
+            "end_to_end_achieved": (acc["alg"] / 1e9) / dt,
+        }
+        if cpu is not None:
+            O = cpu["O"]
+            cores = a.cpu_threads or min(os.cpu_count() or 1, 16)
+            checked = 0
+            if O.have_ref():
+                # part 2: all cores (OpenMP -t), reads 0 (fwd, noisy), 1 (rc), 2 (fwd) of the pool, one after another
+                idxs = list(range(min(a.cpu_reads, len(batches[0]["reads"]))))
+                t_multi = 0.0
+                for i in idxs:
+                    r = batches[0]["reads"][i]
+                    job = RefJob(O, a, r["post"], r["rc"], cores, cpu["tmp"])
+                    rc_, lines = job.wait()
+                    t_multi += job.wall
+                    assert rc_ == 0 and lines == as_lines(outs[0][i]), "GPU list of read %d differs from the reference" % i
+                    checked += 1
+                res["cpu_baseline"] = dict(value=len(idxs) / t_multi, unit="reads/s", cores=cores, kind="reference",
+                                           sample="%d reads of the benchmark pool (fwd noisy, rc, fwd), -t %d, one after another; wall %.1f s"
+                                                  % (len(idxs), cores, t_multi), host_cpus=os.cpu_count())
+                rc_, lines = cpu["job1"].wait(timeout=900)
+                i1 = cpu["i1"]
+                assert rc_ == 0 and lines == as_lines(outs[0][i1]), "GPU list of read %d differs from the reference" % i1
+                checked += 1
+                res["cpu_baseline_single_thread"] = dict(
+                    value=1.0 / cpu["job1"].wall, unit="reads/s", cores=1, kind="reference",
+                    sample="1 read (rc, noisy, nblk=%d), -t 1, run beside the GPU leg on its own core; wall %.1f s"
+                           % (batches[0]["reads"][i1]["post"].shape[0], cpu["job1"].wall))
+            else:
+                # the reference binary did not travel: time the plain-C restatement instead, and say so loudly
+                code = O.OracleCode(a.mem_conv, a.rate, a.msg_len, rc=bool(batches[0]["reads"][0]["rc"]))
+                t1 = time.time()
+                lst, _ = code.decode(batches[0]["reads"][0]["post"], a.list_size, a.max_deviation, num_threads=cores)
+                wall = time.time() - t1
+                assert ["".join(map(str, x)) for x in lst] == as_lines(outs[0][0]), "GPU list differs from the oracle"
+                checked += 1
+                res["cpu_baseline"] = dict(value=1.0 / wall, unit="reads/s", cores=cores, kind="port",
+                                           warning="oracle/_ref/viterbi_nanopore.out is absent on this host: this is the C restatement, NOT the reference binary",
+                                           sample="1 read, %d threads; wall %.1f s" % (cores, wall))
+            res["config"]["reference_checked_reads"] = checked
+        print(json.dumps(res), flush=True)
+    if a.resident:
+        for bt in batches:
+            dec.free(bt["dev"])
     dec.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

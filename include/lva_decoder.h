@@ -78,6 +78,12 @@ typedef struct lva_profile {
                                  matches, fingerprint collision */
   int32_t slots;              /* reads in flight */
   int32_t kernel;             /* kernel mode used */
+  /* with lva_decoder_set_launch_events(d, 1): HIP events around every trellis-step launch */
+  double dominant_kernel_ms;  /* sum over launches of the dominant kernel alone (lva_step_fast / lva_step_big / ...) */
+  double step_pair_ms;        /* sum over launches of dominant kernel + fix-up pass */
+  uint64_t timed_launches;    /* launches in those sums */
+  double h2d_ms;              /* lva_decode_batch: HIP-event time of the host->device copy of the posteriors */
+  uint64_t h2d_bytes;
 } lva_profile;
 
 const char *lva_version(void);
@@ -141,6 +147,9 @@ int lva_decode_windows_device(lva_decoder *d, const float *post_dev, const int64
                               int32_t *out_counts);
 
 int lva_decoder_profile(const lva_decoder *d, lva_profile *out);
+/* on != 0: record HIP events around every trellis-step launch of later decode calls (three per launch, on the
+ * decoder's stream) so that lva_profile carries per-kernel times measured live; off by default. */
+int lva_decoder_set_launch_events(lva_decoder *d, int32_t on);
 
 /* Device helpers so that callers without a HIP binding (ctypes) can keep inputs resident. */
 int lva_device_alloc(lva_decoder *d, uint64_t bytes, void **out_dev_ptr);

@@ -18,7 +18,7 @@ ERRORS = {
 EXPORTS = [
     "lva_version", "lva_strerror", "lva_last_hip_error", "lva_code_describe", "lva_code_tables",
     "lva_encode", "lva_algorithmic_bytes", "lva_decoder_create", "lva_decoder_destroy",
-    "lva_decode_batch", "lva_decode_batch_device", "lva_decoder_profile", "lva_device_alloc",
+    "lva_decode_batch", "lva_decode_batch_device", "lva_decoder_profile", "lva_decoder_set_launch_events", "lva_device_alloc",
     "lva_device_free", "lva_device_upload", "lva_device_synchronize",
     "lva_decode_windows_device", "lva_basecall_batch", "lva_basecall_batch_device", "lva_find_barcode_batch",
     "lva_locate_payload_batch", "lva_locate_payload_batch_device",
@@ -59,7 +59,9 @@ class Profile(ctypes.Structure):
                 ("step_launches", ctypes.c_uint64), ("read_steps", ctypes.c_uint64),
                 ("algorithmic_bytes", ctypes.c_double), ("fixup_states", ctypes.c_uint64),
                 ("fixup_reason", ctypes.c_uint64 * 4),
-                ("slots", ctypes.c_int32), ("kernel", ctypes.c_int32)]
+                ("slots", ctypes.c_int32), ("kernel", ctypes.c_int32),
+                ("dominant_kernel_ms", ctypes.c_double), ("step_pair_ms", ctypes.c_double),
+                ("timed_launches", ctypes.c_uint64), ("h2d_ms", ctypes.c_double), ("h2d_bytes", ctypes.c_uint64)]
 
 
 class PayloadPos(ctypes.Structure):
@@ -101,6 +103,7 @@ def load_library():
     L.lva_decode_batch.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp]
     L.lva_decode_batch_device.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp]
     L.lva_decoder_profile.argtypes = [vp, ctypes.POINTER(Profile)]
+    L.lva_decoder_set_launch_events.argtypes = [vp, i32]
     L.lva_device_alloc.argtypes = [vp, u64, ctypes.POINTER(vp)]
     L.lva_device_free.argtypes = [vp, vp]
     L.lva_device_upload.argtypes = [vp, vp, vp, u64]

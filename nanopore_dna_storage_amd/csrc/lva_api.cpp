@@ -50,18 +50,34 @@ struct lva_decoder {
   int slots = 0;
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev_total0 = nullptr, ev_total1 = nullptr, ev_step0 = nullptr, ev_step1 = nullptr;
+  hipEvent_t ev_total0 = nullptr, ev_total1 = nullptr, ev_step0 = nullptr, ev_step1 = nullptr, ev_h2d = nullptr;
   DevCode* d_codes = nullptr;
   uint16_t* d_predtab = nullptr;
   uint32_t* d_trellis = nullptr;
   uint32_t* d_results = nullptr;
   size_t results_cap = 0;      // reads
+  SlotDesc* d_slots = nullptr; // [slots]
+  uint32_t* d_band = nullptr;  // band tables of the batch in flight: lo | hi << 16 per (read, time step)
+  size_t band_cap = 0;         // words
   WorkHdr* d_work = nullptr;   // header followed by the item array
   uint32_t work_cap = 1u << 20;
   int kernel = 1;              // 1 = exact, 2 = fast + exact fix-up
-  uint32_t launch_no = 0;
+  uint32_t launch_no = 0;      // trellis-step launches since creation (the slots' clock)
+  int launch_events = 0;       // lva_decoder_set_launch_events
+  std::vector<hipEvent_t> ev_pool;
   lva_profile prof{};
 };
+
+namespace {
+// every error exit of a call that has enqueued asynchronous work drains the stream first: pending
+// device->host copies target buffers that die with the call's frame
+struct StreamDrain {
+  hipStream_t s;
+  bool armed = true;
+  explicit StreamDrain(hipStream_t st) : s(st) {}
+  ~StreamDrain() { if (armed && s) (void)hipStreamSynchronize(s); }
+};
+}  // namespace
 
 extern "C" {
 
@@ -206,8 +222,8 @@ int lva_decoder_create(const lva_config* cfg, lva_decoder** out) {
   auto fail = [&](int code) { lva_decoder_destroy(d); return code; };
   if (hipSetDevice(d->device) != hipSuccess) return fail(LVA_ERR_NO_DEVICE);
   if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) return fail(LVA_ERR_HIP);
-  (void)hipEventCreate(&d->ev_total0); (void)hipEventCreate(&d->ev_total1);
-  (void)hipEventCreate(&d->ev_step0); (void)hipEventCreate(&d->ev_step1);
+  for (hipEvent_t* ev : {&d->ev_total0, &d->ev_total1, &d->ev_step0, &d->ev_step1, &d->ev_h2d})
+    if (hipEventCreate(ev) != hipSuccess) return fail(LVA_ERR_HIP);
   {
     const int st = upload_codes(d);
     if (st != LVA_OK) return fail(st);
@@ -216,12 +232,19 @@ int lva_decoder_create(const lva_config* cfg, lva_decoder** out) {
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return fail(LVA_ERR_HIP);
   const uint64_t slot_bytes = d->g.sSlot * sizeof(uint32_t);
   uint64_t budget = cfg->mem_budget_bytes ? cfg->mem_budget_bytes : (uint64_t)(free_b * 0.6);
-  int slots = (int)std::min<uint64_t>(budget / slot_bytes, kMaxSlots);
+  // reads in flight: enough of them that one trellis-step launch fills the chip -- a launch has
+  // (2^m / 64 tiles) x (<= 2 max_deviation positions) x slots workgroups, so small trellises take
+  // proportionally more slots (32 at m >= 11, 256 at m = 8, 1024 at m = 6); bounded by the memory
+  // budget and by the work-list item format (21 - m bits of slot index)
+  const uint64_t hard = std::min<uint64_t>(kMaxSlotsLimit, 1ull << (21 - std::min(c.mem_conv, 20)));
+  int slots = (int)std::min<uint64_t>(budget / slot_bytes, hard);
   if (cfg->max_slots > 0) slots = std::min(slots, (int)cfg->max_slots);
-  else slots = std::min(slots, 32);
+  else slots = std::min<int>(slots, (int)std::max<uint64_t>(32, std::min<uint64_t>(1024, 32ull * 2048 / c.nconv)));
   if (slots < 1) return fail(LVA_ERR_NOMEM);
   d->slots = slots;
   if (hipMalloc(&d->d_trellis, (size_t)slots * slot_bytes) != hipSuccess) return fail(LVA_ERR_NOMEM);
+  if (hipMalloc(&d->d_slots, (size_t)slots * sizeof(SlotDesc)) != hipSuccess) return fail(LVA_ERR_NOMEM);
+  if (hipMemset(d->d_slots, 0, (size_t)slots * sizeof(SlotDesc)) != hipSuccess) return fail(LVA_ERR_HIP);
   d->prof.slots = slots;
   const bool fast_ok = fast_kernel_available(d->g);
   if (cfg->kernel == 2 && !fast_ok) return fail(LVA_ERR_UNSUPPORTED);
@@ -245,6 +268,10 @@ void lva_decoder_destroy(lva_decoder* d) {
   if (d->d_trellis) (void)hipFree(d->d_trellis);
   if (d->d_results) (void)hipFree(d->d_results);
   if (d->d_work) (void)hipFree(d->d_work);
+  if (d->d_slots) (void)hipFree(d->d_slots);
+  if (d->d_band) (void)hipFree(d->d_band);
+  for (hipEvent_t e : d->ev_pool) (void)hipEventDestroy(e);
+  if (d->ev_h2d) (void)hipEventDestroy(d->ev_h2d);
   if (d->d_codes) (void)hipFree(d->d_codes);
   if (d->d_predtab) (void)hipFree(d->d_predtab);
   if (d->ev_total0) (void)hipEventDestroy(d->ev_total0);
@@ -253,6 +280,12 @@ void lva_decoder_destroy(lva_decoder* d) {
   if (d->ev_step1) (void)hipEventDestroy(d->ev_step1);
   if (d->stream) (void)hipStreamDestroy(d->stream);
   delete d;
+}
+
+int lva_decoder_set_launch_events(lva_decoder* d, int32_t on) {
+  if (!d) return LVA_ERR_ARG;
+  d->launch_events = on ? 1 : 0;
+  return LVA_OK;
 }
 
 int lva_decoder_profile(const lva_decoder* d, lva_profile* out) {
@@ -298,87 +331,130 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
   const Geometry& g = d->g;
   const uint32_t npos = d->code[0].npos, L = g.L;
   const size_t rec_words = (size_t)8 * L * g.F;
+  StreamDrain drain(d->stream);
   // reads the reference would refuse (:600-601)
   std::vector<int32_t> order;
+  size_t band_words = 0;
   for (int32_t i = 0; i < n; ++i) {
     const int64_t nb = len[i];
     if (nb < 0 || nb > 0xFFFFFFFFll || beg[i] < 0) return LVA_ERR_ARG;
     if ((uint64_t)nb < (uint64_t)npos + 1) out_counts[i] = LVA_ERR_POST_TOO_SHORT;
-    else { out_counts[i] = 0; order.push_back(i); }
+    else { out_counts[i] = 0; order.push_back(i); band_words += (size_t)nb; }
   }
   // longest first: the tail of the schedule is then made of short reads
   std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return len[a] > len[b]; });
 
   if ((size_t)n > d->results_cap) {
     if (d->d_results) (void)hipFree(d->d_results);
-    d->d_results = nullptr;
+    d->d_results = nullptr; d->results_cap = 0;
     HIP_TRY(hipMalloc(&d->d_results, (size_t)n * rec_words * sizeof(uint32_t)));
     d->results_cap = (size_t)n;
   }
   if (!timed_total_started) HIP_TRY(hipEventRecord(d->ev_total0, d->stream));
-  {
-    WorkHdr h0;
-    std::memset(&h0, 0, sizeof h0);
-    h0.cap = d->work_cap;
-    HIP_TRY(hipMemcpyAsync(d->d_work, &h0, sizeof h0, hipMemcpyHostToDevice, d->stream));
-    HIP_TRY(hipStreamSynchronize(d->stream));   // h0 is on the stack
-    d->launch_no = 0;
-  }
 
-  struct Slot { int32_t read = -1; uint32_t t = 0, nblk = 0, orient = 0, prev_hi = 1; };
+  // band of every time step of every read (:677-679), evaluated here as the reference binary does
+  std::vector<uint32_t> band(std::max<size_t>(band_words, 1));
+  std::vector<size_t> band_at((size_t)n, 0);
+  {
+    size_t at = 0;
+    for (int32_t r : order) {
+      band_at[(size_t)r] = at;
+      const Code& c = d->code[rc_flags && rc_flags[r] ? 1 : 0];
+      const uint32_t nb = (uint32_t)len[r];
+      for (uint32_t t = 0; t < nb; ++t) {
+        uint32_t lo, hi;
+        c.band(t, nb, d->max_dev, &lo, &hi);
+        band[at + t] = lo | (hi << 16);
+      }
+      at += nb;
+    }
+  }
+  if (band.size() > d->band_cap) {
+    if (d->d_band) (void)hipFree(d->d_band);
+    d->d_band = nullptr; d->band_cap = 0;
+    HIP_TRY(hipMalloc(&d->d_band, band.size() * sizeof(uint32_t)));
+    d->band_cap = band.size();
+  }
+  HIP_TRY(hipMemcpyAsync(d->d_band, band.data(), band.size() * sizeof(uint32_t), hipMemcpyHostToDevice, d->stream));
+  WorkHdr h0;
+  std::memset(&h0, 0, sizeof h0);
+  h0.cap = d->work_cap;
+  HIP_TRY(hipMemcpyAsync(d->d_work, &h0, sizeof h0, hipMemcpyHostToDevice, d->stream));
+  HIP_TRY(hipMemsetAsync(d->d_slots, 0, (size_t)d->slots * sizeof(SlotDesc), d->stream));   // nblk = 0: no slot takes part yet
+
+  struct Slot { int32_t read = -1; uint32_t end = 0; };     // end: launch number after the read's last step
   std::vector<Slot> slot((size_t)std::min<size_t>((size_t)d->slots, std::max<size_t>(order.size(), 1)));
   size_t next = 0;
   std::vector<uint8_t> gathered((size_t)n, 0);
   d->prof.step_launches = 0; d->prof.read_steps = 0; d->prof.algorithmic_bytes = 0; d->prof.fixup_states = 0;
+  d->prof.dominant_kernel_ms = 0; d->prof.step_pair_ms = 0; d->prof.timed_launches = 0;
+  const uint32_t band_max = std::min<uint32_t>(npos, 2 * d->max_dev);
   bool first_step = true;
-  size_t active = 0;
+  size_t active = 0, ev_used = 0;
+  auto next_event = [&](hipEvent_t* out) -> int {
+    if (ev_used == d->ev_pool.size()) {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreate(&e));
+      d->ev_pool.push_back(e);
+    }
+    *out = d->ev_pool[ev_used++];
+    return LVA_OK;
+  };
   for (;;) {
-    // (re)fill idle slots
+    // (re)fill idle slots: the read's descriptor and initial scores (:657-663) go in stream order
     for (size_t s = 0; s < slot.size(); ++s) {
       if (slot[s].read >= 0 || next >= order.size()) continue;
       const int32_t r = order[next++];
-      slot[s].read = r; slot[s].t = 0; slot[s].nblk = (uint32_t)len[r];
-      slot[s].orient = rc_flags && rc_flags[r] ? 1u : 0u; slot[s].prev_hi = 1;
-      const int e = launch_init_slot(g, d->d_codes, d->d_trellis, (uint32_t)s, slot[s].orient, d->stream);
+      SlotDesc sd;
+      sd.post = post_dev + (size_t)beg[r] * 40;
+      sd.band = d->d_band + band_at[(size_t)r];
+      sd.nblk = (uint32_t)len[r]; sd.orient = rc_flags && rc_flags[r] ? 1u : 0u;
+      sd.start = d->launch_no; sd.pad = 0;
+      slot[s].read = r; slot[s].end = d->launch_no + sd.nblk;
+      const int e = launch_init_slot(g, d->d_codes, d->d_trellis, (uint32_t)s, sd, d->d_slots, d->stream);
       if (e) { g_hip_error = hipGetErrorString((hipError_t)e); return LVA_ERR_HIP; }
-      d->prof.algorithmic_bytes += d->code[slot[s].orient].algorithmic_bytes(slot[s].nblk, L, d->max_dev);
+      d->prof.algorithmic_bytes += d->code[sd.orient].algorithmic_bytes(sd.nblk, L, d->max_dev);
       ++active;
     }
     if (active == 0) break;
     StepArgs a;
-    a.nslots = 0; a.band_max = 0; a.step_parity = d->launch_no++ & 1u; a.pad = 0;
-    for (size_t s = 0; s < slot.size(); ++s) {
-      if (slot[s].read < 0) continue;
-      SlotStep& ss = a.s[a.nslots++];
-      uint32_t lo, hi;
-      d->code[slot[s].orient].band(slot[s].t, slot[s].nblk, d->max_dev, &lo, &hi);
-      ss.post_row = post_dev + ((size_t)beg[slot[s].read] + slot[s].t) * 40;
-      ss.slot = (uint32_t)s; ss.t = slot[s].t; ss.lo = lo; ss.hi = hi; ss.prev_hi = slot[s].prev_hi;
-      ss.orient = slot[s].orient;
-      if (hi > lo) a.band_max = std::max(a.band_max, hi - lo);
-      slot[s].prev_hi = hi;   // what step t+1 may read as written
+    a.slots = d->d_slots; a.nslots = (uint32_t)slot.size(); a.band_max = band_max;
+    a.launch_no = d->launch_no; a.step_parity = d->launch_no & 1u;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    if (d->launch_events) {
+      int st;
+      if ((st = next_event(&e0)) || (st = next_event(&e1)) || (st = next_event(&e2))) return st;
+      HIP_TRY(hipEventRecord(e0, d->stream));
+      if (first_step) HIP_TRY(hipEventRecord(d->ev_step0, d->stream));
+    } else if (first_step) {
+      HIP_TRY(hipEventRecord(d->ev_step0, d->stream));
     }
-    if (first_step) { HIP_TRY(hipEventRecord(d->ev_step0, d->stream)); first_step = false; }
+    first_step = false;
     {
       const int e = d->kernel == 2
-                        ? launch_step_fast(a, g, d->d_codes, d->d_trellis, d->d_work, reinterpret_cast<uint32_t*>(d->d_work + 1), d->stream)
+                        ? launch_step_fast(a, g, d->d_codes, d->d_trellis, d->d_work, reinterpret_cast<uint32_t*>(d->d_work + 1), d->stream, e1)
                         : d->kernel == 3 ? launch_step_wave(a, g, d->d_codes, d->d_trellis, d->stream)
                                          : launch_step_exact(a, g, d->d_codes, d->d_trellis, d->stream);
       if (e) { g_hip_error = hipGetErrorString((hipError_t)e); return LVA_ERR_HIP; }
     }
+    if (e2) {
+      if (d->kernel != 2) HIP_TRY(hipEventRecord(e1, d->stream));
+      HIP_TRY(hipEventRecord(e2, d->stream));
+    }
+    ++d->launch_no;
     d->prof.step_launches += 1;
-    d->prof.read_steps += a.nslots;
+    d->prof.read_steps += active;
     // retire finished reads
     for (size_t s = 0; s < slot.size(); ++s) {
-      if (slot[s].read < 0) continue;
-      if (++slot[s].t < slot[s].nblk) continue;
-      uint32_t lo, hi;
-      d->code[slot[s].orient].band(slot[s].nblk - 1, slot[s].nblk, d->max_dev, &lo, &hi);
-      if (lo <= npos - 1 && npos - 1 < hi) {   // otherwise the final state was never written: empty list
-        GatherArgs ga{(uint32_t)s, (uint32_t)(slot[s].nblk & 1u), slot[s].orient, (uint32_t)slot[s].read};
+      if (slot[s].read < 0 || slot[s].end != d->launch_no) continue;
+      const int32_t r = slot[s].read;
+      const uint32_t nb = (uint32_t)len[r], orient = rc_flags && rc_flags[r] ? 1u : 0u;
+      const uint32_t last = band[band_at[(size_t)r] + nb - 1];
+      if ((last & 0xFFFFu) <= npos - 1 && npos - 1 < (last >> 16)) {   // otherwise the final state was never written: empty list
+        GatherArgs ga{(uint32_t)s, (uint32_t)(nb & 1u), orient, (uint32_t)r};
         const int e = launch_gather_final(g, d->d_codes, d->d_trellis, ga, d->d_results, d->stream);
         if (e) { g_hip_error = hipGetErrorString((hipError_t)e); return LVA_ERR_HIP; }
-        gathered[(size_t)slot[s].read] = 1;
+        gathered[(size_t)r] = 1;
       }
       slot[s].read = -1;
       --active;
@@ -391,6 +467,7 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
   HIP_TRY(hipMemcpyAsync(&h1, d->d_work, sizeof h1, hipMemcpyDeviceToHost, d->stream));
   HIP_TRY(hipEventRecord(d->ev_total1, d->stream));
   HIP_TRY(hipStreamSynchronize(d->stream));
+  drain.armed = false;
   d->prof.fixup_states = h1.total;
   for (int i = 0; i < 4; ++i) d->prof.fixup_reason[i] = h1.reason[i];
   float ms = 0;
@@ -398,6 +475,14 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
   d->prof.step_kernel_ms = ms;
   HIP_TRY(hipEventElapsedTime(&ms, d->ev_total0, d->ev_total1));
   d->prof.total_ms = ms;
+  for (size_t i = 0; i + 3 <= ev_used; i += 3) {
+    float a_ms = 0, b_ms = 0;
+    HIP_TRY(hipEventElapsedTime(&a_ms, d->ev_pool[i], d->ev_pool[i + 1]));
+    HIP_TRY(hipEventElapsedTime(&b_ms, d->ev_pool[i], d->ev_pool[i + 2]));
+    d->prof.dominant_kernel_ms += a_ms;
+    d->prof.step_pair_ms += b_ms;
+    d->prof.timed_launches += 1;
+  }
 
   for (int32_t i = 0; i < n; ++i) {
     if (out_counts[i] < 0) continue;
@@ -438,11 +523,15 @@ int lva_decode_batch(lva_decoder* d, const float* post, const int64_t* row_offse
   hipError_t e = hipEventRecord(d->ev_total0, d->stream);
   if (e == hipSuccess && blocks > 0)
     e = hipMemcpyAsync(dev, post, (size_t)blocks * 40 * sizeof(float), hipMemcpyHostToDevice, d->stream);
-  if (e != hipSuccess) { g_hip_error = hipGetErrorString(e); (void)hipFree(dev); return LVA_ERR_HIP; }
+  if (e == hipSuccess) e = hipEventRecord(d->ev_h2d, d->stream);
+  if (e != hipSuccess) { g_hip_error = hipGetErrorString(e); (void)hipStreamSynchronize(d->stream); (void)hipFree(dev); return LVA_ERR_HIP; }
   std::vector<int64_t> len((size_t)n_reads);
   for (int32_t i = 0; i < n_reads; ++i) len[i] = row_offsets[i + 1] - row_offsets[i];
   const int st = decode_impl(d, dev, row_offsets, len.data(), n_reads, rc_flags, out_msgs, out_scores, out_counts, true);
   (void)hipStreamSynchronize(d->stream);
+  float ms = 0;
+  d->prof.h2d_ms = (st == LVA_OK && hipEventElapsedTime(&ms, d->ev_total0, d->ev_h2d) == hipSuccess) ? ms : 0.0;
+  d->prof.h2d_bytes = (uint64_t)blocks * 40 * sizeof(float);
   (void)hipFree(dev);
   return st;
 }

@@ -32,7 +32,7 @@
 
 namespace lva {
 
-constexpr int kMaxSlots = 64;
+constexpr int kMaxSlotsLimit = 4096;   // reads in flight (the work-list item format allows 2^(21-m))
 
 struct DevCode {                 // one per orientation (0 = forward, 1 = reverse complement)
   uint32_t m, nconv, npos, init, fin;
@@ -43,7 +43,21 @@ struct DevCode {                 // one per orientation (0 = forward, 1 = revers
   const uint16_t* predtab[4];    // device pointers, [nconv] each (nullptr when unused)
 };
 
-struct SlotStep {                // what one read slot does in one trellis-step launch
+// One per read slot, resident in device memory: written (by lva_init_slot) when a read enters the
+// slot, read by every trellis-step launch.  A launch carries only its number; the slot's time step
+// is t = launch_no - start, and the slot takes part while t < nblk -- so the host enqueues the
+// whole schedule of a batch without per-launch argument tables, for any number of slots.
+struct SlotDesc {
+  const float* post;             // block 0 of the read's posterior matrix (device)
+  const uint32_t* band;          // [nblk] lo | hi << 16: the band of every time step (:677-679), evaluated on
+                                 // the host exactly as the reference binary does (Code::band)
+  uint32_t nblk, orient;
+  uint32_t start;                // launch number of the read's time step 0
+  uint32_t pad;
+};
+
+struct SlotStep {                // what one read slot does in one trellis-step launch (built in registers
+                                 // from the SlotDesc by load_slot, lva_kernels.hip)
   const float* post_row;         // 40 log-posteriors of block t (device)
   uint32_t slot;                 // trellis buffer index
   uint32_t t;
@@ -53,11 +67,11 @@ struct SlotStep {                // what one read slot does in one trellis-step 
 };
 
 struct StepArgs {
-  uint32_t nslots;
-  uint32_t band_max;             // max over slots of hi-lo
-  uint32_t step_parity;          // launch counter & 1: selects the work-list counter
-  uint32_t pad;
-  SlotStep s[kMaxSlots];
+  const SlotDesc* slots;         // device
+  uint32_t nslots;               // slots in use by this batch (grid z)
+  uint32_t band_max;             // positions per band at most (grid y)
+  uint32_t step_parity;          // launch_no & 1: selects the work-list counter
+  uint32_t launch_no;
 };
 
 struct Geometry {                // strides in 32-bit words

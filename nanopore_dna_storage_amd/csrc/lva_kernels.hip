@@ -123,6 +123,25 @@ __device__ __forceinline__ void slot_buffers(const SlotStep& ss, const Geometry&
   *cur = base + (uint64_t)((ss.t + 1) & 1u) * g.sPar;
 }
 
+// This launch's time step of read slot z, or false when the slot takes no part (no read yet, or its read
+// has finished).  Uniform per workgroup: scalar loads.
+__device__ __forceinline__ bool load_slot(const StepArgs& a, uint32_t z, SlotStep* ss) {
+  const SlotDesc& d = a.slots[z];
+  const uint32_t t = a.launch_no - d.start;
+  if (t >= d.nblk) return false;
+  const uint32_t b = d.band[t];
+  ss->post_row = d.post + (size_t)t * 40;
+  ss->slot = z; ss->t = t; ss->lo = b & 0xFFFFu; ss->hi = b >> 16;
+  ss->prev_hi = t ? d.band[t - 1] >> 16 : 1u;       // what step t-1 wrote (only position 0 is initialised at t = 0)
+  ss->orient = d.orient;
+  return true;
+}
+
+// work-list item: (((slot << 8 | band position index) << 3 | crf) << m) | conv
+__device__ __forceinline__ uint32_t make_item(uint32_t m, uint32_t z, uint32_t y, uint32_t k, uint32_t c) {
+  return ((((z << 8) | y) << 3 | k) << m) | c;
+}
+
 // ---- entry addressing: block base -> plane q of conv state c (2 words) ----
 __device__ __forceinline__ uint32_t plane_off(const Geometry& g, uint32_t q, uint32_t c) { return 2 * g.N * q + 2 * c; }
 
@@ -287,7 +306,8 @@ __device__ __noinline__ void exact_state(const Geometry& g, const SlotStep& ss, 
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lva_step_exact(StepArgs args, Geometry g, const DevCode* __restrict__ codes,
                                                       uint32_t* __restrict__ trellis) {
-  const SlotStep& ss = args.s[blockIdx.z];
+  SlotStep ss;
+  if (!load_slot(args, blockIdx.z, &ss)) return;
   const uint32_t pos = ss.lo + blockIdx.y;
   if (pos >= ss.hi) return;
   const uint32_t c = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -303,7 +323,7 @@ __global__ __launch_bounds__(256) void lva_step_exact(StepArgs args, Geometry g,
 
 // ---------------------------------------------------------------------------------------
 // fix-up kernel: exact path over the fast kernel's work list, ONE WAVEFRONT PER TARGET.
-// item = slotidx<<25 | posidx<<17 | crf<<14 | conv.   Requires 2 <= L <= 8.
+// item: make_item().   Requires 2 <= L <= 8.
 // All 64 lanes run the same (uniform) merge on register-resident candidate heads (one per lane,
 // v_readlane access); loads and stores of the 8x8 candidate entries are spread over the lanes, so
 // one target costs a few memory round trips instead of a few hundred.
@@ -323,7 +343,8 @@ __global__ __launch_bounds__(256) void lva_step_fixup(StepArgs args, Geometry g,
     for (uint64_t idx = gid; idx < total; idx += stride) {
       const uint32_t si = (uint32_t)(idx / per_slot);
       const uint32_t rem = (uint32_t)(idx % per_slot);
-      const SlotStep& ss = args.s[si];
+      SlotStep ss;
+      if (!load_slot(args, si, &ss)) continue;
       const uint32_t c = rem % g.N, k = (rem / g.N) & 7u, pos = ss.lo + rem / (g.N * 8);
       if (pos >= ss.hi) continue;
       const uint32_t* prev; uint32_t* cur;
@@ -346,8 +367,10 @@ __global__ __launch_bounds__(256) void lva_step_fixup(StepArgs args, Geometry g,
   auto wru = [lane](uint32_t& v, uint32_t ln, uint32_t x) { v = lane == ln ? x : v; };
   for (uint32_t idx = blockIdx.x * 4 + wv; idx < n; idx += nwaves) {
     const uint32_t it = items[idx];
-    const SlotStep& ss = args.s[it >> 25];
-    const uint32_t pos = ss.lo + ((it >> 17) & 0xFFu), k = (it >> 14) & 7u, c = it & 0x3FFFu;
+    const uint32_t mm = codes[0].m;
+    SlotStep ss;
+    if (!load_slot(args, it >> (mm + 11), &ss)) continue;
+    const uint32_t pos = ss.lo + ((it >> (mm + 3)) & 0xFFu), k = (it >> mm) & 7u, c = it & ((1u << mm) - 1u);
     const uint32_t* prev; uint32_t* cur;
     slot_buffers(ss, g, trellis, &prev, &cur);
     if (!resolve_target(codes[ss.orient], g, ss, pos, c, k, &tg)) continue;   // (uniform per wavefront)
@@ -591,7 +614,8 @@ __device__ __forceinline__ void wave_target(const Geometry& g, const SlotStep& s
 // grid: x = groups of 4 conv states, y = band position index * 8 + crf state, z = slot.
 __global__ __launch_bounds__(256) void lva_step_wave(StepArgs args, Geometry g, const DevCode* __restrict__ codes,
                                                      uint32_t* __restrict__ trellis) {
-  const SlotStep& ss = args.s[blockIdx.z];
+  SlotStep ss;
+  if (!load_slot(args, blockIdx.z, &ss)) return;
   const uint32_t pos = ss.lo + (blockIdx.y >> 3), k = blockIdx.y & 7u;
   if (pos >= ss.hi) return;
   const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -621,7 +645,8 @@ __global__ __launch_bounds__(256) void lva_step_fixup_wave(StepArgs args, Geomet
     for (uint64_t idx = gid; idx < total; idx += stride) {
       const uint32_t si = (uint32_t)(idx / per_slot);
       const uint32_t rem = (uint32_t)(idx % per_slot);
-      const SlotStep& ss = args.s[si];
+      SlotStep ss;
+      if (!load_slot(args, si, &ss)) continue;
       const uint32_t c = rem % g.N, k = (rem / g.N) & 7u, pos = ss.lo + rem / (g.N * 8);
       if (pos >= ss.hi) continue;
       const uint32_t* prev; uint32_t* cur;
@@ -633,8 +658,10 @@ __global__ __launch_bounds__(256) void lva_step_fixup_wave(StepArgs args, Geomet
   const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u, nwaves = gridDim.x * 4;
   for (uint32_t idx = blockIdx.x * 4 + wv; idx < n; idx += nwaves) {
     const uint32_t it = items[idx];
-    const SlotStep& ss = args.s[it >> 25];
-    const uint32_t pos = ss.lo + ((it >> 17) & 0xFFu), k = (it >> 14) & 7u, c = it & 0x3FFFu;
+    const uint32_t mm = codes[0].m;
+    SlotStep ss;
+    if (!load_slot(args, it >> (mm + 11), &ss)) continue;
+    const uint32_t pos = ss.lo + ((it >> (mm + 3)) & 0xFFu), k = (it >> mm) & 7u, c = it & ((1u << mm) - 1u);
     const uint32_t* prev; uint32_t* cur;
     slot_buffers(ss, g, trellis, &prev, &cur);
     if (!resolve_target(codes[ss.orient], g, ss, pos, c, k, &tg)) continue;   // (uniform per wavefront)
@@ -986,11 +1013,12 @@ __global__ __launch_bounds__(8 * TS) void lva_step_fast(StepArgs args, Geometry 
                                                      uint32_t* __restrict__ items) {
   __shared__ uint2 s_src[8 * LL * TS];
   __shared__ float s_post[40];
-  const SlotStep& ss = args.s[blockIdx.z];
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
     hdr->count[args.step_parity ^ 1u] = 0;     // the other parity's list was consumed by the last fix-up
     hdr->overflow[args.step_parity ^ 1u] = 0;
   }
+  SlotStep ss;
+  if (!load_slot(args, blockIdx.z, &ss)) return;
   const uint32_t pos = ss.lo + blockIdx.y;
   if (pos >= ss.hi) return;
   const DevCode& cd = codes[ss.orient];
@@ -1037,7 +1065,7 @@ __global__ __launch_bounds__(8 * TS) void lva_step_fast(StepArgs args, Geometry 
   if (why) {
     atomicAdd(&hdr->reason[why - 1], 1ull);
     const uint32_t idx = atomicAdd(&hdr->count[args.step_parity], 1u);
-    if (idx < hdr->cap) items[idx] = (blockIdx.z << 25) | (blockIdx.y << 17) | (k << 14) | c;
+    if (idx < hdr->cap) items[idx] = make_item(cd.m, blockIdx.z, blockIdx.y, k, c);
     else hdr->overflow[args.step_parity] = 1u;
   }
 }
@@ -1228,11 +1256,12 @@ __global__ __launch_bounds__(8 * TSB) void lva_step_big(StepArgs args, Geometry 
                                                       uint32_t* __restrict__ items) {
   __shared__ uint8_t s_acc[LL * 8 * TSB], s_rej0[LL * 8 * TSB], s_rej1[LL * 8 * TSB];
   __shared__ float s_post[40];
-  const SlotStep& ss = args.s[blockIdx.z];
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
     hdr->count[args.step_parity ^ 1u] = 0;     // the other parity's list was consumed by the last fix-up
     hdr->overflow[args.step_parity ^ 1u] = 0;
   }
+  SlotStep ss;
+  if (!load_slot(args, blockIdx.z, &ss)) return;
   const uint32_t pos = ss.lo + blockIdx.y;
   if (pos >= ss.hi) return;
   const DevCode& cd = codes[ss.orient];
@@ -1264,14 +1293,16 @@ __global__ __launch_bounds__(8 * TSB) void lva_step_big(StepArgs args, Geometry 
   if (why) {
     atomicAdd(&hdr->reason[why - 1], 1ull);
     const uint32_t idx = atomicAdd(&hdr->count[args.step_parity], 1u);
-    if (idx < hdr->cap) items[idx] = (blockIdx.z << 25) | (blockIdx.y << 17) | (t.k << 14) | t.c;
+    if (idx < hdr->cap) items[idx] = make_item(cd.m, blockIdx.z, blockIdx.y, t.k, t.c);
     else hdr->overflow[args.step_parity] = 1u;
   }
 }
 
 // (:657-663) score 0 at (pos 0, initial conv state, every crf state, list entry 0), empty message
 __global__ void lva_init_slot(Geometry g, const DevCode* __restrict__ codes, uint32_t* __restrict__ trellis,
-                              uint32_t slot, uint32_t orient) {
+                              uint32_t slot, SlotDesc desc, SlotDesc* __restrict__ slots) {
+  const uint32_t orient = desc.orient;
+  if (threadIdx.x == 0) slots[slot] = desc;             // the read enters the slot: later step launches see it
   const DevCode& cd = codes[orient];
   uint32_t* par0 = trellis + (uint64_t)slot * g.sSlot;   // parity 0 is "prev" at t = 0
   const uint32_t n = 8 * g.L * g.F;
@@ -1365,7 +1396,7 @@ static int launch_big_p(const StepArgs& a, const Geometry& g, const DevCode* cod
 }
 
 int launch_step_fast(const StepArgs& a, const Geometry& g, const DevCode* codes, uint32_t* trellis, WorkHdr* hdr,
-                     uint32_t* items, void* stream) {
+                     uint32_t* items, void* stream, void* ev_mid) {
   if (a.nslots == 0 || a.band_max == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   int e;
@@ -1374,6 +1405,7 @@ int launch_step_fast(const StepArgs& a, const Geometry& g, const DevCode* codes,
       : g.L <= 32 ? launch_big_p<32>(a, g, codes, trellis, hdr, items, st)
                   : launch_big_p<64>(a, g, codes, trellis, hdr, items, st);
     if (e) return e;
+    if (ev_mid && (e = (int)hipEventRecord((hipEvent_t)ev_mid, st))) return e;
     hipLaunchKernelGGL(lva_step_fixup_wave, dim3(4096), dim3(256), 0, st, a, g, codes, trellis, hdr, items);
     return (int)hipGetLastError();
   }
@@ -1385,6 +1417,7 @@ int launch_step_fast(const StepArgs& a, const Geometry& g, const DevCode* codes,
     default: return (int)hipErrorInvalidValue;
   }
   if (e) return e;
+  if (ev_mid && (e = (int)hipEventRecord((hipEvent_t)ev_mid, st))) return e;
   if (g.L > 1) {   // fix-up pass: exits at once when the work list is empty
     hipLaunchKernelGGL(lva_step_fixup, dim3(256), dim3(256), 0, st, a, g, codes, trellis, hdr, items);
     e = (int)hipGetLastError();
@@ -1392,9 +1425,9 @@ int launch_step_fast(const StepArgs& a, const Geometry& g, const DevCode* codes,
   return e;
 }
 
-int launch_init_slot(const Geometry& g, const DevCode* codes, uint32_t* trellis, uint32_t slot, uint32_t orient,
-                     void* stream) {
-  hipLaunchKernelGGL(lva_init_slot, dim3(1), dim3(64), 0, (hipStream_t)stream, g, codes, trellis, slot, orient);
+int launch_init_slot(const Geometry& g, const DevCode* codes, uint32_t* trellis, uint32_t slot, const SlotDesc& desc,
+                     SlotDesc* slots, void* stream) {
+  hipLaunchKernelGGL(lva_init_slot, dim3(1), dim3(64), 0, (hipStream_t)stream, g, codes, trellis, slot, desc, slots);
   return (int)hipGetLastError();
 }
 

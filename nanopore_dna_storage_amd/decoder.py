@@ -156,8 +156,16 @@ class Decoder:
     def decode(self, posts, rc=None):
         """posts: list of float32 [nblk_i, 40] matrices (.post layout).  rc: optional bool per read.
         -> list of (msgs uint8[count, msg_len], scores float32[count]) or a negative error code per read."""
-        n = len(posts)
         flat, off = self._pack(posts)
+        return self.decode_packed(flat, off, rc)
+
+    pack = _pack
+
+    def decode_packed(self, flat, off, rc=None):
+        """decode() on a host buffer that is already in the C ABI's form: `flat` float32 [sum nblk, 40] (all reads
+        back to back), `off` int64 [n+1] block offsets.  The host->device copy happens inside the call."""
+        n = len(off) - 1
+        assert flat.dtype == np.float32 and flat.flags.c_contiguous and off.dtype == np.int64
         rcf = None if rc is None else np.ascontiguousarray(rc, dtype=np.uint8)
         msgs, scores, counts = self._outputs(n)
         st = self._L.lva_decode_batch(self._h, flat.ctypes.data, off.ctypes.data, n,
@@ -291,6 +299,10 @@ class Decoder:
         for i, r in zip(good, dec):
             out[i] = (loc[i], r)
         return out
+
+    def set_launch_events(self, on=True):
+        """HIP events around every trellis-step launch of later decode calls (profile(): dominant_kernel_ms, step_pair_ms)"""
+        self._check(self._L.lva_decoder_set_launch_events(self._h, int(bool(on))))
 
     def profile(self):
         p = _lib.Profile()

@@ -1,15 +1,27 @@
 """Multi-GPU sharding of independent reads.
 
-Reads are independent units -- the reference itself scales by running separate processes on
-disjoint read-id files (util/extra/generate_read_id_files.py:23-36, merge_lists.py:11-21).
-One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box, "gloo"
-in CPU tests): reads are dealt to ranks longest-first so every rank gets the same work, each
-rank decodes its shard with no data-path collective, and the decoded lists (about 230 B per
-read) are gathered on rank 0 -- the path's only exchange step.
+Reads are independent units -- the reference itself scales by running separate driver processes on
+disjoint read-id files and merging their lists afterwards:
+  * util/extra/generate_read_id_files.py:23-36   contiguous chunks of the read list, one file per worker
+  * util/extra/pick_new_reads.py:8-9,21          strided chunks (lst[i::n]) of the reads not done yet
+  * util/extra/merge_lists.py:11-21              worker after worker, list_<i>_<j> -> list_<done+j>
+Here: one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box, "gloo"
+in CPU tests and when several ranks share one GPU), each rank decodes its shard with no data-path
+collective, and the decoded lists (about 230 B per read) are gathered on rank 0 in input order --
+the path's only exchange step.  `launch_ranks` starts the rank processes (the reference's "run N
+copies of the driver") from a parent that has not touched the GPU.
 """
+import os
+import socket
+import subprocess
+import sys
+
 import numpy as np
 
 
+# ---------------------------------------------------------------------------------------------
+# who decodes what
+# ---------------------------------------------------------------------------------------------
 def shard_reads(nblks, world):
     """-> list of index arrays, one per rank.  Longest reads first, dealt round-robin in a
     serpentine order so per-rank sums of nblk (the work) are balanced."""
@@ -21,6 +33,21 @@ def shard_reads(nblks, world):
     return [np.asarray(sorted(s), dtype=np.int64) for s in shards]
 
 
+def shard_strided(n, world):
+    """pick_new_reads.py's chunkify: rank r takes reads r, r+world, r+2*world, ...  Needs no knowledge of
+    the read lengths, so every rank can build (or load) only its own reads."""
+    return [np.arange(r, n, world, dtype=np.int64) for r in range(world)]
+
+
+def shard_contiguous(n, world):
+    """generate_read_id_files.py: consecutive blocks of ceil(n/world) reads, the last one shorter."""
+    per = -(-n // world) if world else 0
+    return [np.arange(min(r * per, n), min((r + 1) * per, n), dtype=np.int64) for r in range(world)]
+
+
+# ---------------------------------------------------------------------------------------------
+# results <-> fixed-shape arrays (what travels in the gather)
+# ---------------------------------------------------------------------------------------------
 def pack_results(results, list_size, msg_len):
     """list of (msgs, scores) | error code -> (counts int32[n], msgs uint8[n, L, msg_len], scores f32[n, L])"""
     n = len(results)
@@ -28,7 +55,7 @@ def pack_results(results, list_size, msg_len):
     msgs = np.zeros((n, list_size, msg_len), np.uint8)
     scores = np.zeros((n, list_size), np.float32)
     for i, r in enumerate(results):
-        if isinstance(r, int):
+        if isinstance(r, (int, np.integer)):
             counts[i] = r
         else:
             counts[i] = len(r[0])
@@ -45,40 +72,108 @@ def unpack_results(counts, msgs, scores):
     return out
 
 
-def decode_sharded(decode_fn, posts, rc, list_size, msg_len, dist=None, device=None):
-    """Decode `posts` across the ranks of an initialised torch.distributed group.
-    decode_fn(posts_subset, rc_subset) -> list of results (this rank's Decoder.decode).
-    Every rank passes the same posts/rc (or at least the same lengths); rank 0 gets the full
-    result list in input order, other ranks get None."""
+def gather_results(local_results, shards, list_size, msg_len, dist=None, device=None):
+    """The exchange step (merge_lists.py:11-21): every rank contributes the results of ITS shard
+    (`local_results[j]` belongs to global read `shards[rank][j]`); rank 0 returns the full list in
+    global read order, the other ranks return None.  `shards` = the same list of index arrays on
+    every rank.  `device`: where the collective's tensors live ("cuda" for nccl/RCCL, None = CPU for gloo)."""
     import torch
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return decode_fn(posts, rc)
+        out = [None] * sum(len(s) for s in shards)
+        for idx, item in zip(shards[0], local_results):
+            out[int(idx)] = item
+        return out
     world, rank = dist.get_world_size(), dist.get_rank()
-    shards = shard_reads([p.shape[0] for p in posts], world)
-    mine = shards[rank]
-    res = decode_fn([posts[i] for i in mine], [rc[i] for i in mine])
-    counts, msgs, scores = pack_results(res, list_size, msg_len)
-    # pad every shard to the largest so that a plain gather works
-    cap = max(len(s) for s in shards)
+    assert len(shards) == world and len(local_results) == len(shards[rank])
+    counts, msgs, scores = pack_results(local_results, list_size, msg_len)
+    cap = max(max(len(s) for s in shards), 1)         # pad every shard to the largest: a plain gather works
 
     def pad(a):
         out = np.zeros((cap,) + a.shape[1:], a.dtype)
         out[:a.shape[0]] = a
-        return torch.from_numpy(out).to(device) if device is not None else torch.from_numpy(out)
+        t = torch.from_numpy(out)
+        return t.to(device) if device is not None else t
 
-    tensors = [pad(counts), pad(msgs), pad(scores)]
     gathered = []
-    for t in tensors:
+    for t in (pad(counts), pad(msgs), pad(scores)):
         buf = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
         dist.gather(t, buf, dst=0)
         gathered.append(buf)
     if rank != 0:
         return None
-    out = [None] * len(posts)
+    out = [None] * sum(len(s) for s in shards)
     for r in range(world):
-        c = gathered[0][r].cpu().numpy()[:len(shards[r])]
-        m = gathered[1][r].cpu().numpy()[:len(shards[r])]
-        s = gathered[2][r].cpu().numpy()[:len(shards[r])]
+        k = len(shards[r])
+        c = gathered[0][r].cpu().numpy()[:k]
+        m = gathered[1][r].cpu().numpy()[:k]
+        s = gathered[2][r].cpu().numpy()[:k]
         for idx, item in zip(shards[r], unpack_results(c, m, s)):
-            out[idx] = item
+            out[int(idx)] = item
     return out
+
+
+def decode_sharded(decode_fn, posts, rc, list_size, msg_len, dist=None, device=None, shards=None):
+    """Decode `posts` across the ranks of an initialised torch.distributed group.
+    decode_fn(posts_subset, rc_subset) -> list of results (this rank's Decoder.decode).
+    Every rank passes the same posts/rc (entries of other ranks' shards may be None when `shards` is
+    given); rank 0 gets the full result list in input order, other ranks get None."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return decode_fn(posts, rc)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if shards is None:
+        shards = shard_reads([p.shape[0] for p in posts], world)
+    mine = shards[rank]
+    res = decode_fn([posts[i] for i in mine], [rc[i] for i in mine])
+    return gather_results(res, shards, list_size, msg_len, dist=dist, device=device)
+
+
+# ---------------------------------------------------------------------------------------------
+# starting the ranks
+# ---------------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(script, argv, nproc, env=None, capture=False):
+    """Run `script argv...` as `nproc` ranks of one node through torch.distributed.run (one process
+    per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) and wait for them.
+
+    The caller must not have initialised the GPU: the ranks are fresh child processes started with
+    subprocess (never an exec of the current process).  -> the launcher's exit code (and its stdout when
+    capture=True)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(nproc)),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(argv)
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this driver
+    e.setdefault("OMP_NUM_THREADS", "1")
+    if capture:
+        p = subprocess.run(cmd, env=e, stdout=subprocess.PIPE, text=True)
+        return p.returncode, p.stdout
+    return subprocess.run(cmd, env=e).returncode
+
+
+def init_rank(backend=None):
+    """In a rank process started by torch.distributed.run: bind this rank to its GPU and join the group.
+    -> (dist module or None, rank, world, device ordinal, collective tensor device).
+    backend "nccl" (default; = RCCL) needs one GPU per rank; "gloo" lets several ranks share a GPU
+    (tests on a 1-GPU box)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1:
+        return None, 0, 1, local, None
+    import torch
+    import torch.distributed as dist
+    backend = backend or os.environ.get("LVA_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()                      # (does not initialise the GPU)
+    if backend == "nccl":
+        if ndev < world and int(os.environ.get("LOCAL_WORLD_SIZE", world)) > ndev:
+            raise RuntimeError("%d ranks on this node but only %d GPUs: one GPU per rank is required with RCCL "
+                               "(set LVA_DIST_BACKEND=gloo to share a GPU in tests)" % (world, ndev))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        return dist, rank, world, local, "cuda"
+    dist.init_process_group(backend)
+    return dist, rank, world, local % max(ndev, 1), None

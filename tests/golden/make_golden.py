@@ -62,6 +62,14 @@ CASES = [
     ("m11_r5_L64", 11, 5, 180, 64, 20, False, 6.0, 307, {}),
     ("m14_r7_L8", 14, 7, 180, 8, 20, False, 6.0, 401, {}),
     ("m14_r1_L2_short", 14, 1, 20, 2, 10, True, 4.0, 402, {}),
+    # round 2: the expensive settings in the noisy / reverse-complement regime (stale band decides entries 2..L)
+    ("m14_r7_L8_noisy", 14, 7, 180, 8, 20, False, 3.0, 403, {}),
+    ("m14_r7_L8_rc", 14, 7, 180, 8, 20, True, 4.0, 404, {}),
+    ("m14_r7_L4", 14, 7, 180, 4, 20, False, 3.0, 405, {}),          # supplement 5.2: list size 4 at m=14
+    ("m11_r5_L64_noisy", 11, 5, 180, 64, 20, False, 3.0, 308, {}),
+    ("m11_r5_L64_rc", 11, 5, 180, 64, 20, True, 4.0, 309, {}),
+    ("m8_r3_L64", 8, 3, 164, 64, 20, False, 3.0, 206, {}),          # supplement 5.2: list size 64 at m=8
+    ("m8_r3_L64_rc", 8, 3, 164, 64, 20, True, 3.0, 207, {}),
 ]
 
 # decode invocations the reference refuses or aborts on: (name, args..., truncate post to n blocks)

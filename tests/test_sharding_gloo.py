@@ -74,3 +74,42 @@ def test_gather_on_rank0_world2():
     posts, rc = make_inputs()
     want = [(r if isinstance(r, int) else (r[0].tolist(), r[1].tolist())) for r in fake_decode(posts, rc)]
     assert got == want
+
+
+def test_strided_and_contiguous_shards():
+    for n, w in ((11, 3), (8, 8), (5, 8), (0, 2)):
+        for fn in (sharding.shard_strided, sharding.shard_contiguous):
+            sh = fn(n, w)
+            assert len(sh) == w and sorted(np.concatenate(sh).tolist()) == list(range(n))
+    assert sharding.shard_strided(7, 3)[1].tolist() == [1, 4]                 # pick_new_reads.py: lst[i::n]
+    assert sharding.shard_contiguous(7, 3)[2].tolist() == [6]                 # generate_read_id_files.py: last file shorter
+
+
+def test_launch_ranks_world2_gather_in_input_order(tmp_path):
+    """sharding.launch_ranks starts two rank processes (torch.distributed.run, gloo); each decodes a strided shard
+    with the stand-in decoder; rank 0's gathered list equals the single-process result."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    import _rank_worker as W
+    out = str(tmp_path / "g.npz")
+    env = dict(os.environ, LVA_DIST_BACKEND="gloo")
+    rc_ = sharding.launch_ranks(os.path.join(here, "_rank_worker.py"), [out, "fake", "13"], 2, env=env)
+    assert rc_ == 0
+    z = np.load(out)
+    assert int(z["world"]) == 2
+    posts, rc = W.fake_posts(13)
+    c, m, s = sharding.pack_results(W.fake_decode(posts, rc), W.L, W.MSG)
+    assert np.array_equal(z["counts"], c) and np.array_equal(z["msgs"], m) and np.array_equal(z["scores"], s)
+
+
+def test_bench_parent_refuses_mismatched_group(tmp_path):
+    """bench.py run as a rank of a group whose size differs from --gpus stops before touching the GPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode != 0 and "launcher started 1 ranks" in p.stderr
