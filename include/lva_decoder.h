@@ -162,7 +162,8 @@ int lva_device_synchronize(lva_decoder *d);
  * flip-flop basecall of the posterior matrix and the barcode localisation on it, so that the
  * whole .post -> payload window -> decoded list chain stays on the device.
  * Posterior matrices are passed as for lva_decode_batch: one float32[blocks][40] buffer and
- * row_offsets[n_reads+1] in blocks (row_offsets[0] = 0).
+ * row_offsets[n_reads+1] in blocks (row_offsets[0] = 0).  A read may have at most 2^20 blocks (or called
+ * bases) and a batch fewer than 2^31 blocks in all; beyond that the calls return LVA_ERR_ARG.
  * ------------------------------------------------------------------------------------------- */
 
 /* Result of a barcode search for one read.

@@ -572,6 +572,10 @@ int lva_device_synchronize(lva_decoder* d) {
 // ---------------------------------------------------------------------------------------------
 namespace {
 
+// bc_search packs (edit distance << 20 | window index) into one word for its minimum reduction
+// (bc_kernels.hip): a read may have at most 2^20 blocks / called bases.  Real reads have a few thousand.
+constexpr int64_t kBcMaxBlocks = (int64_t)1 << 20;
+
 struct DevBlock {              // one device allocation carved into 256-byte aligned pieces
   char* base = nullptr;
   size_t used = 0, cap = 0;
@@ -622,8 +626,9 @@ int bc_run(lva_decoder* d, const float* post_dev, const int64_t* row_offsets, in
   static_assert(sizeof(lva_payload_pos) == sizeof(BcResult), "lva_payload_pos layout");
   if (n == 0) return LVA_OK;
   for (int32_t i = 0; i < n; ++i)
-    if (row_offsets[i + 1] < row_offsets[i]) return LVA_ERR_ARG;
+    if (row_offsets[i + 1] < row_offsets[i] || row_offsets[i + 1] - row_offsets[i] > kBcMaxBlocks) return LVA_ERR_ARG;
   const size_t T = (size_t)(row_offsets[n] - row_offsets[0]);
+  if (T >= ((size_t)1 << 31)) return LVA_ERR_ARG;          // 32-bit block offsets inside the kernels
   if (row_offsets[0] != 0) return LVA_ERR_ARG;
   DevBlock blk;
   blk.cap = DevBlock::pad(8 * ((size_t)n + 1)) + DevBlock::pad(8 * T + 8) + DevBlock::pad(T + n + 1) + DevBlock::pad(T + 1) +
@@ -720,7 +725,7 @@ int lva_find_barcode_batch(lva_decoder* d, const char* bases, const uint32_t* tr
   if (base_offsets[0] != 0) return LVA_ERR_ARG;
   std::vector<int32_t> nb(n_reads);
   for (int32_t i = 0; i < n_reads; ++i) {
-    if (base_offsets[i + 1] < base_offsets[i]) return LVA_ERR_ARG;
+    if (base_offsets[i + 1] < base_offsets[i] || base_offsets[i + 1] - base_offsets[i] > kBcMaxBlocks) return LVA_ERR_ARG;
     nb[i] = (int32_t)(base_offsets[i + 1] - base_offsets[i]);
   }
   const size_t T = (size_t)base_offsets[n_reads], n = (size_t)n_reads;

@@ -1092,6 +1092,12 @@ namespace {
 #ifndef LVA_TSB
 #define LVA_TSB 32
 #endif
+#ifndef LVA_BIG_SHSTORE
+#define LVA_BIG_SHSTORE 1
+#endif
+#ifndef LVA_BIG_GB
+#define LVA_BIG_GB 6
+#endif
 constexpr uint32_t TSB = LVA_TSB;   // source conv states per workgroup tile (workgroup = 8*TSB threads)
 
 template <int LL, int P, int NL>
@@ -1163,7 +1169,15 @@ __device__ __forceinline__ int big_merge(const Geometry& g, const uint32_t* __re
     const bool accept = proceed && !isdup, reject = proceed && isdup;
     const uint32_t from9 = (sel << 6) | j;
     const unsigned long long hi9 = (unsigned long long)(sel >> 2);
-    if (accept) s_acc[lc * NT] = (uint8_t)from9;
+    if (accept) {
+      s_acc[lc * NT] = (uint8_t)from9;
+#if LVA_BIG_SHSTORE
+      // (score, fingerprint) of the accepted entry goes out now: the lanes of a wavefront accept at nearly the same
+      // list index, so the 8-byte pieces of a row meet in L2 -- and the output phase need not read the source
+      // entry again (a 64-lane gather of 8 bytes per 64-byte line)
+      *reinterpret_cast<uint2*>(cur + own_c + mul24(lc, sBlk)) = make_uint2(f2u(M), ch);
+#endif
+    }
     acc_hi |= accept ? hi9 << lc : 0ull;
     const uint32_t ra = lc - 1u - (uint32_t)q;                 // the entry it matched (only meaningful when reject)
     const unsigned long long rbit = 1ull << (ra & 63u);
@@ -1199,7 +1213,7 @@ __device__ __forceinline__ int big_merge(const Geometry& g, const uint32_t* __re
   // outputs, entry l of the whole wavefront at a time (:771-774, :780-783, :799).  Every fingerprint
   // match filed under an entry must be the same message (else: collision, the exact path decides).
   bool good = true;
-  constexpr uint32_t GB = LL >= 64 ? 6 : 4;       // entries whose loads are in flight together (VGPRs: the fingerprints are dead by now)
+  constexpr uint32_t GB = LL >= 64 ? LVA_BIG_GB : 4;       // entries whose loads are in flight together (VGPRs: the fingerprints are dead by now)
   for (uint32_t l0 = 0; l0 < L; l0 += GB) {
     uint32_t m[GB][2 * P], q0[GB][2 * P]; uint2 sh2[GB]; uint32_t iu[GB], ir[GB];
 #pragma unroll
@@ -1209,7 +1223,9 @@ __device__ __forceinline__ int big_merge(const Geometry& g, const uint32_t* __re
       if (l < lc) {
         const uint32_t f = locate((uint32_t)s_acc[l * NT] | ((uint32_t)(acc_hi >> l) & 1u) << 8, &iu[u]);
         const uint32_t cv = iu[u] == 0 ? t.c : t.cp;
+#if !LVA_BIG_SHSTORE
         sh2[u] = *reinterpret_cast<const uint2*>(prev + f + 2 * cv);
+#endif
         load_msg<P>(prev + f + pw, N, cv, iu[u] == 0 ? t.np_dst : t.np_src, m[u]);
         if ((rv0 >> l) & 1ull) {          // the first match filed under this entry: its load travels with the others
           const uint32_t fr = locate((uint32_t)s_rej0[l * NT] | ((uint32_t)(rh0 >> l) & 1u) << 8, &ir[u]);
@@ -1221,8 +1237,10 @@ __device__ __forceinline__ int big_merge(const Geometry& g, const uint32_t* __re
     for (uint32_t u = 0; u < GB; ++u) {
       const uint32_t l = l0 + u;
       if (l < lc) {
+#if !LVA_BIG_SHSTORE
         const float sc = u2f(sh2[u].x) + ladd(iu[u]);
         *reinterpret_cast<uint2*>(cur + own_c + mul24(l, sBlk)) = make_uint2(f2u(sc), iu[u] ? sh2[u].y ^ t.fpc : sh2[u].y);
+#endif
         push_bits<2 * P>(m[u], iu[u] == 0 ? 0u : t.sh, t.nb);
         store_msg<P>(cur + t.own + mul24(l, sBlk) + pw, N, t.c, t.np_dst, m[u]);
         if ((rv0 >> l) & 1ull) {

@@ -16,12 +16,26 @@ start_pos = -1 marks a read whose barcodes were not found.  Everything downstrea
 reference's: the skip rule (:76), helper.truncate_post_file semantics (:84), one decoded list
 file OUT_PREFIX_i per read (:85-90, max-deviation 20), and the info file "readid<TAB>ref" (:56).
 The original flags are kept (those describing the unavailable input side are accepted and ignored).
+
+Beyond the reference:
+  --resume   skip reads whose OUT_PREFIX_i already exists (the reference re-runs by computing the read-ids
+             that are not done yet, util/extra/pick_new_reads.py:11-18; one output file per read is its
+             checkpoint)
+  --gpus N   the reference scales by running N copies of the driver on disjoint read-id files and merging the
+             lists (util/extra/generate_read_id_files.py:23-36, merge_lists.py:11-21); here N rank processes
+             (one per GPU, torch.distributed over RCCL) each decode a strided share of the manifest and rank 0
+             gathers the lists (sharding.decode_sharded) and writes every output file.
 """
 import argparse
+import os
 import sys
 
-from . import helper
+import numpy as np
+
+from . import helper, sharding
 from .decoder import Decoder
+
+BARCODE_FAILURE = -100          # travels in the gather in place of a list: "Failure in barcode removing."
 
 
 def build_parser():
@@ -40,10 +54,12 @@ def build_parser():
     p.add_argument("--end_barcode", type=str, default=None)
     p.add_argument("--max_deviation", type=int, default=20)
     p.add_argument("--device", type=int, default=0)
+    p.add_argument("--resume", action="store_true")
+    p.add_argument("--gpus", type=int, default=1)
     return p
 
 
-def run(args, out=sys.stdout):
+def read_manifest(args):
     rows = []
     with open(args.post_manifest) as f:
         for line in f:
@@ -58,18 +74,26 @@ def run(args, out=sys.stdout):
             else:
                 rid, ref, path, s, e, rc = cols
                 rows.append((rid, ref, path, int(s), int(e), rc not in ("0", "", "False")))
+    return rows
+
+
+def decode_rows(args, rows, device):
+    """the per-read work of generate_decoded_lists.py:50-98 for `rows` on one GPU
+    -> (results: one of list | negative error code | BARCODE_FAILURE per row, located: {row index: window dict})"""
     min_len = args.mem_conv + args.msg_len + 1
-    results = {}
+    results = [BARCODE_FAILURE] * len(rows)
+    located = {}
+    if not rows:
+        return results, located
     with Decoder(args.mem_conv, args.rate_conv, args.msg_len, list_size=args.list_size,
-                 max_deviation=args.max_deviation, device=args.device) as dec:
+                 max_deviation=args.max_deviation, device=device) as dec:
         # rows without a window: basecall + barcode search + decode on the device (:68-89)
         todo = [i for i, r in enumerate(rows) if r[3] is None]
-        located = {}
         if todo:
             chain = dec.decode_with_barcodes([helper.read_post_file(rows[i][2]) for i in todo],
                                              args.start_barcode, args.end_barcode)
             for i, (loc, res) in zip(todo, chain):
-                located[i] = loc
+                located[i] = dict(start_pos=int(loc["start_pos"]), end_pos=int(loc["end_pos"]), rc=bool(loc["rc"]))
                 if res is not None:
                     results[i] = res
         # rows with a window from an earlier search (:76, :84)
@@ -78,32 +102,65 @@ def run(args, out=sys.stdout):
             posts = [helper.truncate_post(helper.read_post_file(rows[i][2]), rows[i][3], rows[i][4]) for i in keep]
             for i, res in zip(keep, dec.decode(posts, rc=[rows[i][5] for i in keep])):
                 results[i] = res
+    return results, located
+
+
+def run(args, out=sys.stdout, dist=None, device=None, coll_dev=None):
+    rows = read_manifest(args)
+    n = len(rows)
+    done = [args.resume and os.path.exists(args.out_prefix + "_" + str(i)) for i in range(n)]
+    work = [i for i in range(n) if not done[i]]
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    shards = sharding.shard_strided(len(work), world)
+    mine = [work[int(j)] for j in shards[rank]]
+    res, loc = decode_rows(args, [rows[i] for i in mine], args.device if device is None else device)
+    loc = {mine[j]: v for j, v in loc.items()}
+    if dist is not None:
+        res = sharding.gather_results(res, shards, args.list_size, args.msg_len, dist=dist, device=coll_dev)
+        locs = [None] * world if rank == 0 else None
+        dist.gather_object(loc, locs, dst=0)
+        if rank != 0:
+            return 0
+        loc = {k: v for d in locs for k, v in d.items()}
+    results = {work[j]: r for j, r in enumerate(res)}
     written = 0
     with open(args.info_file, "w") as f_info:
         for i, (rid, ref, path, s, e, rc) in enumerate(rows):
             print("i:", i, file=out); print(rid, file=out); print(ref, file=out)
             f_info.write(rid + "\t" + ref + "\n")
-            if i in located:
-                loc = located[i]
-                print("start_pos_in_post", loc["start_pos"], file=out); print("end_pos_in_post", loc["end_pos"], file=out)
-                print("--rc" if loc["rc"] else "", file=out)
-            res = results.get(i)
-            if res is None:
-                print("Failure in barcode removing.", file=out)
-                continue
-            if isinstance(res, int):
-                continue       # the reference decoder aborts (no output file) on such a read
+            if done[i]:
+                continue                                   # --resume: the list file of an earlier run stands
+            if i in loc:
+                print("start_pos_in_post", loc[i]["start_pos"], file=out); print("end_pos_in_post", loc[i]["end_pos"], file=out)
+                print("--rc" if loc[i]["rc"] else "", file=out)
+            r = results.get(i, BARCODE_FAILURE)
+            if isinstance(r, (int, np.integer)):
+                if r == BARCODE_FAILURE:
+                    print("Failure in barcode removing.", file=out)
+                continue       # (other codes: the reference decoder aborts, no output file, on such a read)
             with open(args.out_prefix + "_" + str(i), "w") as f:
-                for row in res[0]:
+                for row in r[0]:
                     f.write("".join("1" if b else "0" for b in row) + "\n")
             written += 1
     return written
 
 
 def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
     args = build_parser().parse_args(argv)
-    print(args)
-    run(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # start the ranks as child processes; this parent never touches the GPU
+        return sharding.launch_ranks("nanopore_dna_storage_amd.generate_decoded_lists", argv, args.gpus, module=True)
+    dist, rank, world, device, coll_dev = sharding.init_rank()
+    if rank == 0:
+        print(args)
+    if dist is None:
+        run(args)
+    else:
+        run(args, dist=dist, device=device, coll_dev=coll_dev)
+        dist.barrier()
+        dist.destroy_process_group()
     return 0
 
 

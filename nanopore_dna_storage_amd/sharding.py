@@ -136,15 +136,15 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch_ranks(script, argv, nproc, env=None, capture=False):
-    """Run `script argv...` as `nproc` ranks of one node through torch.distributed.run (one process
+def launch_ranks(script, argv, nproc, env=None, capture=False, module=False):
+    """Run `script argv...` (`python -m script argv...` when module=True) as `nproc` ranks of one node through torch.distributed.run (one process
     per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) and wait for them.
 
     The caller must not have initialised the GPU: the ranks are fresh child processes started with
     subprocess (never an exec of the current process).  -> the launcher's exit code (and its stdout when
     capture=True)."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(nproc)),
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(argv)
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port())] + (["-m"] if module else []) + [script] + list(argv)
     e = dict(os.environ if env is None else env)
     e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this driver
     e.setdefault("OMP_NUM_THREADS", "1")

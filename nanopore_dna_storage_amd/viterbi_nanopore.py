@@ -7,7 +7,11 @@ decode on the GPU.
 
 Exit codes follow the reference: 0 ok; 255 (`return -1`) for parameter errors, with the message
 and usage on stdout; 134 (abort on an uncaught std::runtime_error) for a post matrix that is too
-short / too many states, with no output file written.  Callers of the reference pass '' as an
+short / too many states, with no output file written; 1 (message on stderr, no output file) for
+failures the reference cannot have: no usable GPU, device memory, a HIP error, a list size the C ABI refuses.
+One process per read pays interpreter start-up, HIP initialisation and the decoder's tables and trellis
+allocation every time (measured in DESIGN.md): batch callers should use Decoder.decode or
+generate_decoded_lists, which keep one decoder for all reads.  Callers of the reference pass '' as an
 argv element when the read is not reverse-complemented (simulator.py:82-85); it is ignored here
 as cxxopts ignores it.
 """
@@ -136,7 +140,10 @@ def main(argv=None, out=sys.stdout):
     except LvaError as e:
         if e.code in (-5, -7):
             return 134                            # runtime_error -> abort, no output file
-        raise
+        # errors the reference cannot have (no GPU, out of device memory, HIP failure, list size 0 or > 65535):
+        # message on stderr, exit code 1, no output file -- never a Python traceback
+        print("viterbi_nanopore: %s" % e, file=sys.stderr)
+        return 1
     if isinstance(res, int):
         return 134                                # "Too small post matrix"
     with open(a.outfile, "w") as f:               # :248-253

@@ -430,6 +430,41 @@ static inline void msg_push(uint32_t *dst, const uint32_t *src, uint32_t W, uint
   dst[0] |= newbits;
 }
 
+#ifdef LVA_ORACLE_STATS
+/* merge statistics for kernel design (scripts/merge_stats.py builds a copy of this file with
+ * -DLVA_ORACLE_STATS): how many heap pops a target needs, how deep each candidate list is consumed */
+#define ST_MAXL 65
+uint64_t lva_stats_targets, lva_stats_pops[8 * ST_MAXL + 1], lva_stats_accepted[ST_MAXL + 1];
+uint64_t lva_stats_stay_depth[ST_MAXL + 1], lva_stats_src_depth[ST_MAXL + 1], lva_stats_src_rank_depth[8][ST_MAXL + 1];
+uint64_t lva_stats_src_pops_below[ST_MAXL + 1];     /* [K]: source-list pops with index < K */
+uint64_t lva_stats_src_pops_total, lva_stats_stay_pops_total, lva_stats_targets_src_within[ST_MAXL + 1];
+void lva_oracle_stats_reset(void) {
+  lva_stats_targets = lva_stats_src_pops_total = lva_stats_stay_pops_total = 0;
+  memset(lva_stats_pops, 0, sizeof lva_stats_pops); memset(lva_stats_accepted, 0, sizeof lva_stats_accepted);
+  memset(lva_stats_stay_depth, 0, sizeof lva_stats_stay_depth); memset(lva_stats_src_depth, 0, sizeof lva_stats_src_depth);
+  memset(lva_stats_src_rank_depth, 0, sizeof lva_stats_src_rank_depth);
+  memset(lva_stats_src_pops_below, 0, sizeof lva_stats_src_pops_below);
+  memset(lva_stats_targets_src_within, 0, sizeof lva_stats_targets_src_within);
+}
+static void lva_oracle_stats_record(uint32_t L, int np, const uint32_t *depth, uint32_t pops, uint32_t accepted) {
+  if (L >= ST_MAXL) return;
+#pragma omp critical(lva_stats)
+  {
+    lva_stats_targets++; lva_stats_pops[pops]++; lva_stats_accepted[accepted]++;
+    lva_stats_stay_depth[depth[0]]++; lva_stats_stay_pops_total += depth[0];
+    uint32_t d[8]; int n = 0; uint32_t mx = 0;
+    for (int i = 1; i < np; i++) {
+      d[n++] = depth[i]; lva_stats_src_depth[depth[i]]++; lva_stats_src_pops_total += depth[i];
+      if (depth[i] > mx) mx = depth[i];
+      for (uint32_t K = 0; K <= L; K++) lva_stats_src_pops_below[K] += depth[i] < K ? depth[i] : K;
+    }
+    for (uint32_t K = mx; K <= L; K++) lva_stats_targets_src_within[K]++;
+    for (int a = 0; a < n; a++) for (int b = a + 1; b < n; b++) if (d[b] > d[a]) { uint32_t t = d[a]; d[a] = d[b]; d[b] = t; }
+    for (int a = 0; a < n; a++) lva_stats_src_rank_depth[a][d[a]]++;
+  }
+}
+#endif
+
 int lva_oracle_decode(const lva_oracle_code *c, const float *post, uint32_t nblk, uint32_t L,
                       uint32_t max_deviation, int num_threads, uint32_t max_steps, int band_fma,
                       uint8_t *out_msgs, float *out_scores, uint32_t *out_count) {
@@ -526,8 +561,14 @@ int lva_oracle_decode(const lva_oracle_code *c, const float *post, uint32_t nblk
           }
           heap_build(heap, hn);
           uint32_t l = 0;
+#ifdef LVA_ORACLE_STATS
+          uint32_t st_depth[MAX_PRED] = {0}, st_pops = 0; const int st_heads = hn;
+#endif
           while (hn > 0 && l < L) {
             hnode top = heap_pop(heap, &hn);
+#ifdef LVA_ORACLE_STATS
+            st_depth[top.ps]++; st_pops++;
+#endif
             const pred_t *pi = &pl[top.ps];
             const size_t from = from_of[top.ps];
             msg_push(cand, prev->msg + (from * L + top.j) * W, W, pi->shift, pi->newbits);
@@ -539,6 +580,9 @@ int lva_oracle_decode(const lva_oracle_code *c, const float *post, uint32_t nblk
             if (nxt != NEG)
               heap_push(heap, &hn, (hnode){nxt + pt_row[pi->row * 8 + pi->col], top.ps, top.j + 1});
           }
+#ifdef LVA_ORACLE_STATS
+          if (st_heads > 0) lva_oracle_stats_record(L, np, st_depth, st_pops, l);
+#endif
           for (; l < L; l++) cs[l] = NEG;                                          /* :799 */
         }
       }

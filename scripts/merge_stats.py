@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Merge statistics of the list decoder (kernel design input): builds an instrumented copy of the CPU
+oracle (-DLVA_ORACLE_STATS, into /tmp) and prints, for one synthetic read, how many heap pops a target
+needs and how deep each candidate list is consumed.
+
+    python scripts/merge_stats.py M RATE MSG_LEN L [margin] [threads]
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from nanopore_dna_storage_amd import synth  # noqa: E402
+
+m, r, ml, L = (int(x) for x in sys.argv[1:5])
+margin = float(sys.argv[5]) if len(sys.argv) > 5 else 4.0
+thr = int(sys.argv[6]) if len(sys.argv) > 6 else 4
+so = "/tmp/liblva_oracle_stats.so"
+subprocess.run(["gcc", "-O2", "-std=c11", "-fopenmp", "-fPIC", "-shared", "-fno-fast-math", "-ffp-contract=off",
+                "-DLVA_ORACLE_STATS", "-o", so, os.path.join(ROOT, "oracle", "lva_oracle.c"),
+                os.path.join(ROOT, "oracle", "basecall_oracle.c"), "-lm"], check=True)
+Lb = ctypes.CDLL(so)
+Lb.lva_oracle_code_new.restype = ctypes.c_void_p
+Lb.lva_oracle_code_new.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_char_p, ctypes.c_uint32,
+                                   ctypes.POINTER(ctypes.c_int)]
+Lb.lva_oracle_decode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int,
+                                 ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
+st = ctypes.c_int(0)
+h = Lb.lva_oracle_code_new(m, r, ml, 0, None, 0, ctypes.byref(st))
+rd = synth.make_read(m, r, ml, seed=4242, margin=margin)
+post = np.ascontiguousarray(rd["post"])
+msgs = np.zeros((L, ml), np.uint8); sc = np.zeros(L, np.float32); cnt = ctypes.c_uint32(0)
+Lb.lva_oracle_stats_reset()
+Lb.lva_oracle_decode(h, post.ctypes.data, post.shape[0], L, 20, thr, 0, 1, msgs.ctypes.data, sc.ctypes.data, ctypes.byref(cnt))
+
+
+def arr(name, n):
+    return np.array((ctypes.c_uint64 * n).in_dll(Lb, name), dtype=np.float64)
+
+
+T = float(ctypes.c_uint64.in_dll(Lb, "lva_stats_targets").value)
+pops = arr("lva_stats_pops", 8 * 65 + 1); acc = arr("lva_stats_accepted", 66)
+stay = arr("lva_stats_stay_depth", 66); src = arr("lva_stats_src_depth", 66)
+below = arr("lva_stats_src_pops_below", 66); within = arr("lva_stats_targets_src_within", 66)
+sp = float(ctypes.c_uint64.in_dll(Lb, "lva_stats_src_pops_total").value)
+yp = float(ctypes.c_uint64.in_dll(Lb, "lva_stats_stay_pops_total").value)
+print("m=%d r=%d msg_len=%d L=%d margin=%.1f nblk=%d: targets with a finite head %.3g" % (m, r, ml, L, margin, post.shape[0], T))
+print("mean pops %.2f  mean accepted %.2f  full lists %.1f%%" % ((pops * np.arange(len(pops))).sum() / T,
+                                                               (acc * np.arange(66)).sum() / T, 100 * acc[L] / T))
+print("pops from the stay list %.1f%%, from source lists %.1f%%" % (100 * yp / (yp + sp), 100 * sp / (yp + sp)))
+q = np.cumsum(stay) / T
+print("stay-list depth: mean %.2f  quantiles 50/90/99: %d/%d/%d" % ((stay * np.arange(66)).sum() / T,
+      np.searchsorted(q, .5), np.searchsorted(q, .9), np.searchsorted(q, .99)))
+rk = np.array((ctypes.c_uint64 * (8 * 66)).in_dll(Lb, "lva_stats_src_rank_depth"), dtype=np.float64).reshape(8, 66)
+for a in range(7):
+    if rk[a].sum():
+        print("  source list rank %d: mean depth %.2f, zero %.1f%%" % (a, (rk[a] * np.arange(66)).sum() / rk[a].sum(), 100 * rk[a][0] / rk[a].sum()))
+for K in (1, 2, 4, 8, 12, 16, 24, 32):
+    if K <= L:
+        print("K=%2d: %.1f%% of source-list pops have index < K; %.1f%% of targets never go beyond K in any source list"
+              % (K, 100 * below[K] / max(sp, 1), 100 * within[K] / T))

@@ -71,3 +71,69 @@ def test_bench_weak_mode_cycles_distinct_batches(tmp_path):
                    "--rate", "1", "--msg-len", "60", "--list-size", "4", "--no-cpu-baseline", "--slots", "2"], {}, tmp_path, "weak")
     assert j["scaling"] == "weak" and j["config"]["distinct_reads_per_gpu"] == 15 and j["config"]["reads_per_step_per_gpu"] == 5
     assert z["counts"].shape[0] == 5
+
+
+def _manifest(tmp_path, n=5):
+    """mixed manifest: windows known (6 columns) and untruncated posts (3 columns)"""
+    sb, eb = "CACCTGTGCTGCGTCAGGCTGTGTC", "GCTGTCCGTTCCGCATTGACACGGC"
+    rows, msgs = [], []
+    for i in range(n):
+        p = tmp_path / ("r%d.post" % i)
+        if i % 2 == 0:
+            rd = synth.make_read(6, 1, 60, 300 + i, rc=bool(i & 2), margin=6.0)
+            pad = np.full((3, 40), -3.7, np.float32)
+            np.concatenate([pad, rd["post"], pad]).tofile(p)
+            rows.append("read%d\tref%d\t%s\t%d\t%d\t%d" % (i, i, p, 3, 3 + rd["post"].shape[0] - 1, int(rd["rc"])))
+        else:
+            rd = synth.make_barcoded_read(6, 1, 60, 300 + i, sb, eb, rc=bool(i & 2), margin=6.0, flank=(5, 14))
+            rd["post"].tofile(p)
+            rows.append("read%d\tref%d\t%s" % (i, i, p))
+        msgs.append("".join(map(str, rd["msg"])))
+    man = tmp_path / "manifest.tsv"
+    man.write_text("\n".join(rows) + "\n")
+    return man, msgs, ["--mem_conv", "6", "--msg_len", "60", "--rate_conv", "1", "--list_size", "4",
+                       "--start_barcode", sb, "--end_barcode", eb]
+
+
+def test_generate_decoded_lists_two_ranks_and_resume(tmp_path):
+    """--gpus 2: the driver starts its own rank processes, rank 0 gathers the lists and writes every file;
+    --resume: list files that exist are left alone (the reference's per-read checkpoint, pick_new_reads.py:11-18)."""
+    man, msgs, flags = _manifest(tmp_path)
+    d1, d2 = tmp_path / "one", tmp_path / "two"
+    d1.mkdir(); d2.mkdir()
+    env = dict(os.environ, LVA_DIST_BACKEND="gloo", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    base = [sys.executable, "-m", "nanopore_dna_storage_amd.generate_decoded_lists", "--post_manifest", str(man)] + flags
+    p1 = subprocess.run(base + ["--out_prefix", str(d1 / "list"), "--info_file", str(d1 / "info.txt")], env=env,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p1.returncode == 0, p1.stderr[-2000:]
+    p2 = subprocess.run(base + ["--out_prefix", str(d2 / "list"), "--info_file", str(d2 / "info.txt"), "--gpus", "2"], env=env,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p2.returncode == 0, p2.stderr[-2000:]
+    assert (d1 / "info.txt").read_text() == (d2 / "info.txt").read_text()
+    for i, msg in enumerate(msgs):
+        a, b = (d1 / ("list_%d" % i)).read_text(), (d2 / ("list_%d" % i)).read_text()
+        assert a == b and a.split()[0] == msg
+    # resume: a marker in place of list_1 survives, a deleted list_2 comes back
+    (d1 / "list_1").write_text("kept\n")
+    keep2 = (d1 / "list_2").read_text()
+    (d1 / "list_2").unlink()
+    p3 = subprocess.run(base + ["--out_prefix", str(d1 / "list"), "--info_file", str(d1 / "info.txt"), "--resume"], env=env,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p3.returncode == 0, p3.stderr[-2000:]
+    assert (d1 / "list_1").read_text() == "kept\n" and (d1 / "list_2").read_text() == keep2
+
+
+def test_reference_path_launcher_decodes(tmp_path):
+    """viterbi/viterbi_nanopore.out, the reference's PATH_TO_CPP_EXEC (helper.py:19, simulator.py:30,
+    generate_decoded_lists.py:37), called exactly as helper.py:305 calls it"""
+    from golden_util import GOLDEN, load_case
+    name = "m6_r1_L4_rc"
+    m, post, lines = load_case(name)
+    out_file = tmp_path / "dec"
+    p = subprocess.run([os.path.join(ROOT, "viterbi", "viterbi_nanopore.out"), "-m", "decode", "-i", os.path.join(GOLDEN, name + ".post"),
+                        "-o", str(out_file), "--mem-conv", "6", "--msg-len", "60", "-l", "4", "-t", "8", "-r", "1", "--rc",
+                        "--max-deviation", "20"], stdout=subprocess.PIPE, text=True, timeout=600, cwd=str(tmp_path))
+    assert p.returncode == 0 and p.stdout == "Reverse complement flag detected.\n"
+    assert out_file.read_text() == "".join(ln + "\n" for ln in lines)

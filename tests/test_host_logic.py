@@ -153,3 +153,22 @@ def test_synthetic_generator_is_deterministic_and_normalised():
     st = synth.state_path([0, 0, 0, 1, 1, 2])
     assert list(st) == [0, 4, 0, 1, 5, 2]
     assert synth.transition_index(3, 1) == 1 * 8 + 3 and synth.transition_index(2, 6) == 34 and synth.transition_index(6, 6) == 38
+
+
+def test_reference_path_launcher_encodes(tmp_path):
+    """viterbi/viterbi_nanopore.out (the path the reference's scripts spawn) with -m encode, as simulator.py:67 calls it"""
+    import os
+    import subprocess
+    from golden_util import encode_cases
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    c = encode_cases()["cases"][0]
+    fin, fout = tmp_path / "msg.txt", tmp_path / "oligo.txt"
+    fin.write_text("".join(m + "\n" for m in c["msgs"]))
+    p = subprocess.run([os.path.join(root, "viterbi", "viterbi_nanopore.out"), "-m", "encode", "-i", str(fin), "-o", str(fout),
+                        "--mem-conv", str(c["mem_conv"]), "--msg-len", str(c["msg_len"]), "-r", str(c["rate"])],
+                       stdout=subprocess.PIPE, text=True, cwd=str(tmp_path))
+    assert p.returncode == 0
+    assert fout.read_text().split() == c["oligos"]
+    p = subprocess.run([os.path.join(root, "viterbi", "viterbi_nanopore.out"), "-m", "encode", "-i", str(fin), "-o", str(fout),
+                        "--mem-conv", "7", "--msg-len", "180"], stdout=subprocess.PIPE, text=True, cwd=str(tmp_path))
+    assert p.returncode == 255 and "Invalid mem_conv" in p.stdout
