@@ -1093,7 +1093,7 @@ namespace {
 #define LVA_TSB 32
 #endif
 #ifndef LVA_BIG_SHSTORE
-#define LVA_BIG_SHSTORE 1
+#define LVA_BIG_SHSTORE 0      // 1: accepted (score, fingerprint) pairs stored inside the merge loop: 6.94 instead of 6.14 ms per launch
 #endif
 #ifndef LVA_BIG_GB
 #define LVA_BIG_GB 6
