@@ -204,6 +204,33 @@ int lva_locate_payload_batch_device(lva_decoder *d, const float *post_dev, const
                                     const char *start_barcode, const char *end_barcode, uint32_t min_len,
                                     lva_payload_pos *out);
 
+/* ---------------------------------------------------------------------------------------------
+ * the Reed-Solomon outer code, RS(65535, 65535 - redundancy) over GF(2^16)
+ * (primitive polynomial x^16+x^12+x^3+x+1, generator roots alpha^0 .. alpha^(redundancy-1)) shortened to n_total
+ * symbols -- one codeword per 16-bit column of the oligo payloads, all columns in one call.
+ * Symbols are uint16 in host byte order = the little-endian 2-byte pieces the reference reads from its files
+ * (RSCode_schifra/schifra_RS_16bit_fileio.cpp:89-103).  1 <= redundancy <= 4096, redundancy < n_total <= 65535.
+ * pad_symbol = the value of the 65535 - n_total untransmitted leading symbols (the reference pads with ASCII '0'
+ * bytes: 0x3030, RSCode_16bit_fileio.py:58,:104).
+ * ------------------------------------------------------------------------------------------- */
+
+/* replaces: RS_decode_16bit for every column (RSCode_schifra/RSCode_16bit_fileio.py:87-137) =
+ * schifra decoder::decode(block, erasure_list) (RSCode_schifra/schifra_reed_solomon_decoder.hpp:64-168).
+ *   symbols   [n_codewords][n_total] received words (the reference puts pad_symbol at erased positions, :242-250);
+ *   erasures  n_erasures distinct positions in [0, n_total), shared by all codewords;
+ *   out       [n_codewords][n_total - redundancy] decoded data symbols; where the reference's decoder gives up
+ *             (no output file, :122-123) every symbol is fail_symbol (the reference: ASCII '0' bytes, 0x3030);
+ *   ok        [n_codewords] 1 = decoded, 0 = given up (may be NULL). */
+int lva_rs_decode(int32_t device, const uint16_t *symbols, int32_t n_codewords, int32_t n_total, int32_t redundancy,
+                  const int32_t *erasures, int32_t n_erasures, uint16_t pad_symbol, uint16_t fail_symbol, uint16_t *out,
+                  int32_t *ok);
+
+/* replaces: RS_encode_16bit for every column (RSCode_16bit_fileio.py:48-77) = schifra encoder::encode
+ * (schifra_reed_solomon_encoder.hpp:57-88): systematic; out [n_codewords][n_data + redundancy] = data, then parity. */
+int lva_rs_encode(int32_t device, const uint16_t *data, int32_t n_codewords, int32_t n_data, int32_t redundancy,
+                  uint16_t pad_symbol, uint16_t *out);
+const char *lva_rs_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,7 @@ EXPORTS = [
     "lva_device_free", "lva_device_upload", "lva_device_synchronize",
     "lva_decode_windows_device", "lva_basecall_batch", "lva_basecall_batch_device", "lva_find_barcode_batch",
     "lva_locate_payload_batch", "lva_locate_payload_batch_device",
+    "lva_rs_decode", "lva_rs_encode", "lva_rs_last_error",
 ]
 
 
@@ -114,5 +115,9 @@ def load_library():
     L.lva_find_barcode_batch.argtypes = [vp, vp, vp, vp, i32, cp, cp, vp]
     L.lva_locate_payload_batch.argtypes = [vp, vp, vp, i32, cp, cp, u32, vp]
     L.lva_locate_payload_batch_device.argtypes = [vp, vp, vp, i32, cp, cp, u32, vp]
+    u16 = ctypes.c_uint16
+    L.lva_rs_decode.argtypes = [i32, vp, i32, i32, i32, vp, i32, u16, u16, vp, vp]
+    L.lva_rs_encode.argtypes = [i32, vp, i32, i32, i32, u16, vp]
+    L.lva_rs_last_error.restype = cp
     _lib = L
     return L

@@ -5,5 +5,5 @@ set -e
 cd "$(dirname "$0")/../nanopore_dna_storage_amd/csrc"
 mkdir -p ../../variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function \
-  -Wno-unused-variable $2 -shared -o ../../variants/$1.so lva_api.cpp lva_code.cpp lva_kernels.hip bc_kernels.hip
+  -Wno-unused-variable $2 -shared -o ../../variants/$1.so lva_api.cpp lva_code.cpp lva_kernels.hip bc_kernels.hip rs_kernels.hip
 echo built variants/$1.so
