@@ -237,7 +237,7 @@ def main():
                        "h2d": "excluded (resident)" if a.resident else "included",
                        "h2d_ms_per_step": acc["h2d_ms"] / max(a.steps, 1), "h2d_bytes_per_step": acc["h2d_b"] / max(a.steps, 1),
                        "kernel": prof["kernel"], "fixup_states": acc["fix"], "fixup_reason": fixr,
-                       "gathered_lists": n_global},
+                       "gathered_lists": n_global, "mean_active_slots": acc["read_steps"] / max(acc["launches"], 1)},
         }
         use_events = acc["tl"] > 0
         dom_ms = acc["dom_ms"] if use_events else acc["span_ms"]
