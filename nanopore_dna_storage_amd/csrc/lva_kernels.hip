@@ -321,6 +321,117 @@ __global__ __launch_bounds__(256) void lva_step_exact(StepArgs args, Geometry g,
   if (resolve_target(cd, g, ss, pos, c, b + 4, &tg)) exact_state(g, ss, prev, cur, tg, pos);
 }
 
+// The exact merge of ONE target by ONE WAVEFRONT for list sizes 2..8 (the reference's heap merge :743-800 on
+// lane-resident values).  tg and pos are wavefront-uniform; all 64 lanes must be active.
+__device__ __forceinline__ void fixup_small(const Geometry& g, const SlotStep& ss, const uint32_t* __restrict__ prev,
+                                            uint32_t* __restrict__ cur, const Target& tg, uint32_t lane) {
+  const uint32_t L = g.L, sBlk = g.sBlk, sCrf = (uint32_t)g.sCrf, k = tg.k;
+  const float NEG = -INFINITY;
+  // Everything the merge decides on is wavefront-uniform and lives in registers spread over the
+  // lanes (candidate (list i, index j) in lane i*8+j, heap element e in lane e, accepted entry a
+  // in lane a), read with v_readlane and written with a lane-select: a few cycles per access.
+  auto rdf = [](float v, uint32_t ln) -> float { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)ln)); };
+  auto rdu = [](uint32_t v, uint32_t ln) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)ln); };
+  auto wrf = [lane](float& v, uint32_t ln, float x) { v = lane == ln ? x : v; };          // (clang 22 has no writelane builtin)
+  auto wru = [lane](uint32_t& v, uint32_t ln, uint32_t x) { v = lane == ln ? x : v; };
+  // 1. candidates: lane = list*8 + index; transition score of list i in lane i
+  float cs = NEG; uint32_t cy = 0;
+  {
+    const uint32_t i = lane >> 3, j = lane & 7u;
+    if (i < tg.nlists && ((tg.okmask >> i) & 1u) && j < L) {
+      const uint32_t b = (i == 0 ? tg.own : tg.src + list_crf(k, i) * sCrf) + j * sBlk + 2 * (i == 0 ? tg.c : tg.cp);
+      const uint2 v = *reinterpret_cast<const uint2*>(prev + b);
+      cs = u2f(v.x); cy = i != 0 ? v.y ^ tg.fpc : v.y;
+    }
+  }
+  float addv = 0.0f;
+  if (lane < tg.nlists) addv = ss.post_row[tg.row * 8 + (lane == 0 ? k : list_crf(k, lane))];
+  // word w of the candidate message built from entry (li, lj) -- per lane, for full compares and output
+  auto word_of = [&](uint32_t li, uint32_t lj, uint32_t w) -> uint32_t {
+    const uint32_t b = (li == 0 ? tg.own : tg.src + list_crf(k, li) * sCrf) + lj * sBlk;
+    const uint32_t cv = li == 0 ? tg.c : tg.cp, np = li == 0 ? tg.np_dst : tg.np_src;
+    const uint32_t v = msg_word(g, prev, b, cv, w, np);
+    if (li == 0) return v;
+    const uint32_t lowpart = w == 0 ? tg.newbits : (msg_word(g, prev, b, cv, w - 1, np) >> (32 - tg.shift));
+    return (v << tg.shift) | lowpart;
+  };
+  // 2. the reference merge (:743-800): GCC 11 bits/stl_heap.h restated on lane-resident arrays
+  float hs = NEG; uint32_t hx = 0;                       // heap element e in lane e
+  float as = NEG; uint32_t ay = 0, ax = 0;               // accepted entry a in lane a: score, fingerprint, source
+  auto sift_up = [&](uint32_t hole, uint32_t top, float vs, uint32_t vx) {
+    while (hole > top) {
+      const uint32_t parent = (hole - 1) / 2;
+      const float ps = rdf(hs, parent);
+      if (!(ps < vs)) break;
+      wrf(hs, hole, ps); wru(hx, hole, rdu(hx, parent));
+      hole = parent;
+    }
+    wrf(hs, hole, vs); wru(hx, hole, vx);
+  };
+  auto adjust = [&](uint32_t hole, uint32_t len, float vs, uint32_t vx) {
+    const uint32_t top = hole;
+    uint32_t child = hole;
+    while (child < (len - 1) / 2) {
+      child = 2 * (child + 1);
+      if (rdf(hs, child) < rdf(hs, child - 1)) --child;
+      wrf(hs, hole, rdf(hs, child)); wru(hx, hole, rdu(hx, child));
+      hole = child;
+    }
+    if ((len & 1u) == 0 && child == (len - 2) / 2) {
+      child = 2 * (child + 1);
+      wrf(hs, hole, rdf(hs, child - 1)); wru(hx, hole, rdu(hx, child - 1));
+      hole = child - 1;
+    }
+    sift_up(hole, top, vs, vx);
+  };
+  uint32_t hn = 0;
+  for (uint32_t i = 0; i < tg.nlists; ++i) {                         // :750-761
+    const float head = rdf(cs, i * 8);
+    if (head != NEG) { wrf(hs, hn, head + rdf(addv, i)); wru(hx, hn, i << 16); ++hn; }
+  }
+  if (hn >= 2)                                                       // std::make_heap :762
+    for (uint32_t parent = (hn - 2) / 2;; --parent) {
+      adjust(parent, hn, rdf(hs, parent), rdu(hx, parent));
+      if (parent == 0) break;
+    }
+  uint32_t l = 0;
+  const uint32_t Wd = 2 * tg.np_dst;
+  while (hn > 0 && l < L) {                                          // :764
+    const float ts = rdf(hs, 0); const uint32_t tx = rdu(hx, 0);     // pop_heap + back + pop_back :766-768
+    if (hn > 1) adjust(0, hn - 1, rdf(hs, hn - 1), rdu(hx, hn - 1));
+    --hn;
+    const uint32_t i = tx >> 16, j = tx & 0xFFFFu;
+    const uint32_t ch = rdu(cy, i * 8 + j);
+    bool dup = false;                                                // :778-779
+    unsigned long long match = __ballot(lane < l && ay == ch);      // different fingerprint => different message
+    while (match && !dup) {
+      const uint32_t a = (uint32_t)__builtin_ctzll(match);
+      match &= match - 1;
+      const uint32_t asrc = rdu(ax, a);
+      uint32_t diff = 0;
+      if (lane < Wd) diff = word_of(i, j, lane) ^ word_of(asrc >> 16, asrc & 0xFFFFu, lane);
+      dup = __ballot(diff != 0) == 0ull;
+    }
+    if (!dup) { wrf(as, l, ts); wru(ay, l, ch); wru(ax, l, tx); ++l; }   // :780-783
+    if (j == L - 1) continue;                                        // :788
+    const float nxt = rdf(cs, i * 8 + j + 1);
+    if (nxt != NEG) {                                                // :790-796
+      sift_up(hn, 0, nxt + rdf(addv, i), (i << 16) | (j + 1));
+      ++hn;
+    }
+  }
+  // 3. outputs: lane = entry*8 + word
+  {
+    const uint32_t e = lane >> 3, w = lane & 7u;
+    const float es = __shfl(as, (int)e);
+    const uint32_t ey = __shfl(ay, (int)e), ex = __shfl(ax, (int)e);
+    if (e < L && w == 0)
+      *reinterpret_cast<uint2*>(cur + tg.own + e * sBlk + 2 * tg.c) = e < l ? make_uint2(f2u(es), ey) : make_uint2(kNegInfBits, 0u);
+    if (e < l && w < Wd)
+      cur[tg.own + e * sBlk + 2 * g.N + msg_word_off(g.N, tg.c, w, tg.np_dst)] = word_of(ex >> 16, ex & 0xFFFFu, w);
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // fix-up kernel: exact path over the fast kernel's work list, ONE WAVEFRONT PER TARGET.
 // item: make_item().   Requires 2 <= L <= 8.
@@ -356,15 +467,6 @@ __global__ __launch_bounds__(256) void lva_step_fixup(StepArgs args, Geometry g,
 
   const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const uint32_t nwaves = gridDim.x * 4;
-  const uint32_t L = g.L, sBlk = g.sBlk, sCrf = (uint32_t)g.sCrf;
-  const float NEG = -INFINITY;
-  // Everything the merge decides on is wavefront-uniform and lives in registers spread over the
-  // lanes (candidate (list i, index j) in lane i*8+j, heap element e in lane e, accepted entry a
-  // in lane a), read with v_readlane and written with a lane-select: a few cycles per access.
-  auto rdf = [](float v, uint32_t ln) -> float { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)ln)); };
-  auto rdu = [](uint32_t v, uint32_t ln) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)ln); };
-  auto wrf = [lane](float& v, uint32_t ln, float x) { v = lane == ln ? x : v; };          // (clang 22 has no writelane builtin)
-  auto wru = [lane](uint32_t& v, uint32_t ln, uint32_t x) { v = lane == ln ? x : v; };
   for (uint32_t idx = blockIdx.x * 4 + wv; idx < n; idx += nwaves) {
     const uint32_t it = items[idx];
     const uint32_t mm = codes[0].m;
@@ -375,102 +477,7 @@ __global__ __launch_bounds__(256) void lva_step_fixup(StepArgs args, Geometry g,
     slot_buffers(ss, g, trellis, &prev, &cur);
     if (!resolve_target(codes[ss.orient], g, ss, pos, c, k, &tg)) continue;   // (uniform per wavefront)
     if (pos == 0) continue;              // position 0 never reaches the work list
-    // 1. candidates: lane = list*8 + index; transition score of list i in lane i
-    float cs = NEG; uint32_t cy = 0;
-    {
-      const uint32_t i = lane >> 3, j = lane & 7u;
-      if (i < tg.nlists && ((tg.okmask >> i) & 1u) && j < L) {
-        const uint32_t b = (i == 0 ? tg.own : tg.src + list_crf(k, i) * sCrf) + j * sBlk + 2 * (i == 0 ? tg.c : tg.cp);
-        const uint2 v = *reinterpret_cast<const uint2*>(prev + b);
-        cs = u2f(v.x); cy = i != 0 ? v.y ^ tg.fpc : v.y;
-      }
-    }
-    float addv = 0.0f;
-    if (lane < tg.nlists) addv = ss.post_row[tg.row * 8 + (lane == 0 ? k : list_crf(k, lane))];
-    // word w of the candidate message built from entry (li, lj) -- per lane, for full compares and output
-    auto word_of = [&](uint32_t li, uint32_t lj, uint32_t w) -> uint32_t {
-      const uint32_t b = (li == 0 ? tg.own : tg.src + list_crf(k, li) * sCrf) + lj * sBlk;
-      const uint32_t cv = li == 0 ? tg.c : tg.cp, np = li == 0 ? tg.np_dst : tg.np_src;
-      const uint32_t v = msg_word(g, prev, b, cv, w, np);
-      if (li == 0) return v;
-      const uint32_t lowpart = w == 0 ? tg.newbits : (msg_word(g, prev, b, cv, w - 1, np) >> (32 - tg.shift));
-      return (v << tg.shift) | lowpart;
-    };
-    // 2. the reference merge (:743-800): GCC 11 bits/stl_heap.h restated on lane-resident arrays
-    float hs = NEG; uint32_t hx = 0;                       // heap element e in lane e
-    float as = NEG; uint32_t ay = 0, ax = 0;               // accepted entry a in lane a: score, fingerprint, source
-    auto sift_up = [&](uint32_t hole, uint32_t top, float vs, uint32_t vx) {
-      while (hole > top) {
-        const uint32_t parent = (hole - 1) / 2;
-        const float ps = rdf(hs, parent);
-        if (!(ps < vs)) break;
-        wrf(hs, hole, ps); wru(hx, hole, rdu(hx, parent));
-        hole = parent;
-      }
-      wrf(hs, hole, vs); wru(hx, hole, vx);
-    };
-    auto adjust = [&](uint32_t hole, uint32_t len, float vs, uint32_t vx) {
-      const uint32_t top = hole;
-      uint32_t child = hole;
-      while (child < (len - 1) / 2) {
-        child = 2 * (child + 1);
-        if (rdf(hs, child) < rdf(hs, child - 1)) --child;
-        wrf(hs, hole, rdf(hs, child)); wru(hx, hole, rdu(hx, child));
-        hole = child;
-      }
-      if ((len & 1u) == 0 && child == (len - 2) / 2) {
-        child = 2 * (child + 1);
-        wrf(hs, hole, rdf(hs, child - 1)); wru(hx, hole, rdu(hx, child - 1));
-        hole = child - 1;
-      }
-      sift_up(hole, top, vs, vx);
-    };
-    uint32_t hn = 0;
-    for (uint32_t i = 0; i < tg.nlists; ++i) {                         // :750-761
-      const float head = rdf(cs, i * 8);
-      if (head != NEG) { wrf(hs, hn, head + rdf(addv, i)); wru(hx, hn, i << 16); ++hn; }
-    }
-    if (hn >= 2)                                                       // std::make_heap :762
-      for (uint32_t parent = (hn - 2) / 2;; --parent) {
-        adjust(parent, hn, rdf(hs, parent), rdu(hx, parent));
-        if (parent == 0) break;
-      }
-    uint32_t l = 0;
-    const uint32_t Wd = 2 * tg.np_dst;
-    while (hn > 0 && l < L) {                                          // :764
-      const float ts = rdf(hs, 0); const uint32_t tx = rdu(hx, 0);     // pop_heap + back + pop_back :766-768
-      if (hn > 1) adjust(0, hn - 1, rdf(hs, hn - 1), rdu(hx, hn - 1));
-      --hn;
-      const uint32_t i = tx >> 16, j = tx & 0xFFFFu;
-      const uint32_t ch = rdu(cy, i * 8 + j);
-      bool dup = false;                                                // :778-779
-      unsigned long long match = __ballot(lane < l && ay == ch);      // different fingerprint => different message
-      while (match && !dup) {
-        const uint32_t a = (uint32_t)__builtin_ctzll(match);
-        match &= match - 1;
-        const uint32_t asrc = rdu(ax, a);
-        uint32_t diff = 0;
-        if (lane < Wd) diff = word_of(i, j, lane) ^ word_of(asrc >> 16, asrc & 0xFFFFu, lane);
-        dup = __ballot(diff != 0) == 0ull;
-      }
-      if (!dup) { wrf(as, l, ts); wru(ay, l, ch); wru(ax, l, tx); ++l; }   // :780-783
-      if (j == L - 1) continue;                                        // :788
-      const float nxt = rdf(cs, i * 8 + j + 1);
-      if (nxt != NEG) {                                                // :790-796
-        sift_up(hn, 0, nxt + rdf(addv, i), (i << 16) | (j + 1));
-        ++hn;
-      }
-    }
-    // 3. outputs: lane = entry*8 + word
-    {
-      const uint32_t e = lane >> 3, w = lane & 7u;
-      const float es = __shfl(as, (int)e);
-      const uint32_t ey = __shfl(ay, (int)e), ex = __shfl(ax, (int)e);
-      if (e < L && w == 0)
-        *reinterpret_cast<uint2*>(cur + tg.own + e * sBlk + 2 * tg.c) = e < l ? make_uint2(f2u(es), ey) : make_uint2(kNegInfBits, 0u);
-      if (e < l && w < Wd)
-        cur[tg.own + e * sBlk + 2 * g.N + msg_word_off(g.N, tg.c, w, tg.np_dst)] = word_of(ex >> 16, ex & 0xFFFFu, w);
-    }
+    fixup_small(g, ss, prev, cur, tg, lane);
   }
 }
 
