@@ -162,3 +162,25 @@ def test_many_short_reads_through_few_slots(oracle):
     for x, g in zip(reads, got):
         wm, ws = codes[x["rc"]].decode(x["post"], 4, 6)
         assert np.array_equal(g[0], wm) and np.array_equal(g[1].view(np.uint32), ws.view(np.uint32))
+
+
+@pytest.mark.parametrize("L", [4, 12])
+def test_hundreds_of_slots(oracle, L):
+    """small trellises take hundreds of read slots per launch (device slot table, 21 - m bits of slot index in the
+    work-list items): 300 reads of different lengths through 200 slots, ties included, both the small- and big-list kernels"""
+    reads = [synth.make_read(6, 1, 24, 9000 + i, rc=bool(i % 3 == 0), margin=2.5 + (i % 4), quantum=0.5 if i % 5 == 0 else None)
+             for i in range(300)]
+    with pkg.Decoder(6, 1, 24, list_size=L, max_deviation=6, max_slots=200) as dec:
+        assert dec.profile()["slots"] == 200
+        got = dec.decode([x["post"] for x in reads], rc=[x["rc"] for x in reads])
+        assert dec.profile()["fixup_states"] > 0              # the exact path was exercised from high slot numbers too
+    codes = {rc: oracle.OracleCode(6, 1, 24, rc=rc) for rc in (False, True)}
+    for x, g in zip(reads, got):
+        wm, ws = codes[x["rc"]].decode(x["post"], L, 6)
+        assert np.array_equal(g[0], wm) and np.array_equal(g[1].view(np.uint32), ws.view(np.uint32))
+
+
+def test_default_slot_count_grows_for_small_trellises():
+    for m, r, ml, want in ((6, 1, 60, 1024), (8, 1, 100, 256), (11, 1, 40, 32)):
+        with pkg.Decoder(m, r, ml, list_size=2, max_deviation=20) as dec:
+            assert dec.profile()["slots"] == want
