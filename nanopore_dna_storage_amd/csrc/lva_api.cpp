@@ -57,6 +57,7 @@ struct lva_decoder {
   uint32_t* d_results = nullptr;
   size_t results_cap = 0;      // reads
   SlotDesc* d_slots = nullptr; // [slots]
+  SlotStep* d_steps = nullptr; // [slots] this launch's time step of every slot (lva_prepare_step)
   uint32_t* d_band = nullptr;  // band tables of the batch in flight: lo | hi << 16 per (read, time step)
   size_t band_cap = 0;         // words
   WorkHdr* d_work = nullptr;   // header followed by the item array
@@ -245,6 +246,7 @@ int lva_decoder_create(const lva_config* cfg, lva_decoder** out) {
   if (hipMalloc(&d->d_trellis, (size_t)slots * slot_bytes) != hipSuccess) return fail(LVA_ERR_NOMEM);
   if (hipMalloc(&d->d_slots, (size_t)slots * sizeof(SlotDesc)) != hipSuccess) return fail(LVA_ERR_NOMEM);
   if (hipMemset(d->d_slots, 0, (size_t)slots * sizeof(SlotDesc)) != hipSuccess) return fail(LVA_ERR_HIP);
+  if (hipMalloc(&d->d_steps, (size_t)slots * sizeof(SlotStep)) != hipSuccess) return fail(LVA_ERR_NOMEM);
   d->prof.slots = slots;
   const bool fast_ok = fast_kernel_available(d->g);
   if (cfg->kernel == 2 && !fast_ok) return fail(LVA_ERR_UNSUPPORTED);
@@ -269,6 +271,7 @@ void lva_decoder_destroy(lva_decoder* d) {
   if (d->d_results) (void)hipFree(d->d_results);
   if (d->d_work) (void)hipFree(d->d_work);
   if (d->d_slots) (void)hipFree(d->d_slots);
+  if (d->d_steps) (void)hipFree(d->d_steps);
   if (d->d_band) (void)hipFree(d->d_band);
   for (hipEvent_t e : d->ev_pool) (void)hipEventDestroy(e);
   if (d->ev_h2d) (void)hipEventDestroy(d->ev_h2d);
@@ -418,8 +421,12 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
     }
     if (active == 0) break;
     StepArgs a;
-    a.slots = d->d_slots; a.nslots = (uint32_t)slot.size(); a.band_max = band_max;
+    a.slots = d->d_slots; a.steps = d->d_steps; a.nslots = (uint32_t)slot.size(); a.band_max = band_max;
     a.launch_no = d->launch_no; a.step_parity = d->launch_no & 1u;
+    {
+      const int e = launch_prepare_step(a, d->d_steps, d->stream);
+      if (e) { g_hip_error = hipGetErrorString((hipError_t)e); return LVA_ERR_HIP; }
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     if (d->launch_events) {
       int st;

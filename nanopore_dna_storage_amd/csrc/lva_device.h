@@ -68,6 +68,9 @@ struct SlotStep {                // what one read slot does in one trellis-step 
 
 struct StepArgs {
   const SlotDesc* slots;         // device
+  const SlotStep* steps;         // device, [nslots]: this launch's SlotStep of every slot, written by lva_prepare_step
+                                 // right before the launch (t = 0xFFFFFFFF: the slot takes no part) -- one 32-byte record per
+                                 // workgroup instead of the dependent chain  descriptor -> band[t], band[t-1]
   uint32_t nslots;               // slots in use by this batch (grid z)
   uint32_t band_max;             // positions per band at most (grid y)
   uint32_t step_parity;          // launch_no & 1: selects the work-list counter

@@ -124,17 +124,10 @@ __device__ __forceinline__ void slot_buffers(const SlotStep& ss, const Geometry&
 }
 
 // This launch's time step of read slot z, or false when the slot takes no part (no read yet, or its read
-// has finished).  Uniform per workgroup: scalar loads.
+// has finished).  Uniform per workgroup: one scalar load of the record lva_prepare_step wrote.
 __device__ __forceinline__ bool load_slot(const StepArgs& a, uint32_t z, SlotStep* ss) {
-  const SlotDesc& d = a.slots[z];
-  const uint32_t t = a.launch_no - d.start;
-  if (t >= d.nblk) return false;
-  const uint32_t b = d.band[t];
-  ss->post_row = d.post + (size_t)t * 40;
-  ss->slot = z; ss->t = t; ss->lo = b & 0xFFFFu; ss->hi = b >> 16;
-  ss->prev_hi = t ? d.band[t - 1] >> 16 : 1u;       // what step t-1 wrote (only position 0 is initialised at t = 0)
-  ss->orient = d.orient;
-  return true;
+  *ss = a.steps[z];
+  return ss->t != 0xFFFFFFFFu;
 }
 
 // work-list item: (((slot << 8 | band position index) << 3 | crf) << m) | conv
@@ -681,6 +674,9 @@ __global__ __launch_bounds__(256) void lva_step_fixup_wave(StepArgs args, Geomet
 // ---------------------------------------------------------------------------------------
 namespace {
 
+#ifndef LVA_ACS_KERNEL
+#define LVA_ACS_KERNEL 1       // L == 1 runs lva_step_acs (256-thread workgroups) instead of lva_step_fast<1,P>
+#endif
 constexpr uint32_t TS = 64;      // source conv states per workgroup tile (workgroup = 8*TS threads); 32 measured 10 % slower
 
 // An opaque copy of a register value.  Selecting between two elements of a local array,
@@ -1078,6 +1074,55 @@ __global__ __launch_bounds__(8 * TS) void lva_step_fast(StepArgs args, Geometry 
 }
 
 // ---------------------------------------------------------------------------------------
+// L == 1 (plain Viterbi, :715-742): the same butterfly tile with HALF the threads -- thread (base r, target conv)
+// does the flip target of its (conv, base) and then the flop target.  An add-compare-select is a handful of
+// instructions behind a chain of dependent round trips (slot -> band -> tables -> staging -> barrier -> gather ->
+// store), so what matters is how many tiles a CU has in flight: 256-thread workgroups double that (8 instead of 4
+// per CU).  No ties to resolve (first maximum wins), no work list.
+// grid: x = tiles of 64 source conv states, y = band position index, z = slot index.
+// ---------------------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(4 * TS) void lva_step_acs(StepArgs args, Geometry g, const DevCode* __restrict__ codes,
+                                                       uint32_t* __restrict__ trellis) {
+  __shared__ uint2 s_src[8 * TS];
+  __shared__ float s_post[40];
+  SlotStep ss;
+  if (!load_slot(args, blockIdx.z, &ss)) return;
+  const uint32_t pos = ss.lo + blockIdx.y;
+  if (pos >= ss.hi) return;
+  const DevCode& cd = codes[ss.orient];
+  const uint32_t N = cd.nconv, tid = threadIdx.x, tile = blockIdx.x;
+  const uint32_t* prev; uint32_t* cur;
+  slot_buffers(ss, g, trellis, &prev, &cur);
+  if (pos == 0) {                          // stay-only update of the 8 start states (:706-713)
+    if (tile == cd.init / TS && tid < 8) {
+      const uint32_t k = tid, c = cd.init;
+      const uint32_t own_c = (uint32_t)((uint64_t)k * g.sCrf) + 2 * c;
+      const float s = u2f(prev[own_c]) + ss.post_row[(k >= 4 ? 4u : k) * 8 + k];
+      cur[own_c] = f2u(s);
+      cur[own_c + 1] = prev[own_c + 1];
+      cur[own_c + 2 * N] = prev[own_c + 2 * N];          // plane 1 (the only one in use at position 0)
+      cur[own_c + 2 * N + 1] = prev[own_c + 2 * N + 1];
+    }
+    return;
+  }
+  // stage the (score, fingerprint) pairs of 64 source conv states: 8 crf rows of 512 B, one 16-byte piece per thread
+  const uint32_t src = (uint32_t)((uint64_t)((pos - 1) % g.R) * 8 * g.sCrf);
+  {
+    const uint32_t rowi = tid / (TS / 2), lane2 = tid % (TS / 2);
+    const uint4 v = *reinterpret_cast<const uint4*>(prev + src + (uint64_t)rowi * g.sBlk + 2 * (tile * TS) + 4 * lane2);
+    *reinterpret_cast<uint4*>(&s_src[rowi * TS + 2 * lane2]) = v;
+  }
+  if (tid < 40) s_post[tid] = ss.post_row[tid];
+  __syncthreads();
+  TileTarget t;
+  if (tile_target<TS>(cd, g, ss, pos, tile, tid, &t))                // role 0: the flip target of (base, conv)
+    fast_acs<P, 8>(g, prev, cur, s_src, s_post, t.k, t.c, t.cp, t.sc, t.own, src, t.ok, t.sh, t.nb, t.fpc, t.np_dst, t.np_src);
+  if (tile_target<TS>(cd, g, ss, pos, tile, tid + 4 * TS, &t))       // role 1: the flop target
+    fast_acs<P, 2>(g, prev, cur, s_src, s_post, t.k, t.c, t.cp, t.sc, t.own, src, t.ok, t.sh, t.nb, t.fpc, t.np_dst, t.np_src);
+}
+
+// ---------------------------------------------------------------------------------------
 // big-list fast kernel: list sizes 2 <= L <= 64 that lva_step_fast has no instance for
 // (LL = 16, 32 or 64 >= L is the compile-time capacity).  Same butterfly tiling and the same
 // one-target-per-thread tournament, but a list of 64 entries per state does not fit LDS or
@@ -1323,6 +1368,26 @@ __global__ __launch_bounds__(8 * TSB) void lva_step_big(StepArgs args, Geometry 
   }
 }
 
+// One thread per read slot: resolve descriptor -> time step -> band of this launch into the SlotStep record the
+// step kernels read (small trellises run hundreds of slots per launch, and every workgroup of a slot would otherwise
+// walk the same chain of dependent loads, cold, by itself).
+__global__ void lva_prepare_step(StepArgs a, SlotStep* __restrict__ steps) {
+  const uint32_t z = blockIdx.x * blockDim.x + threadIdx.x;
+  if (z >= a.nslots) return;
+  const SlotDesc d = a.slots[z];
+  const uint32_t t = a.launch_no - d.start;
+  SlotStep ss;
+  ss.post_row = nullptr; ss.slot = z; ss.t = 0xFFFFFFFFu; ss.lo = 0; ss.hi = 0; ss.prev_hi = 0; ss.orient = 0;
+  if (t < d.nblk) {
+    const uint32_t b = d.band[t];
+    ss.post_row = d.post + (size_t)t * 40;
+    ss.t = t; ss.lo = b & 0xFFFFu; ss.hi = b >> 16;
+    ss.prev_hi = t ? d.band[t - 1] >> 16 : 1u;       // what step t-1 wrote (only position 0 is initialised at t = 0)
+    ss.orient = d.orient;
+  }
+  steps[z] = ss;
+}
+
 // (:657-663) score 0 at (pos 0, initial conv state, every crf state, list entry 0), empty message
 __global__ void lva_init_slot(Geometry g, const DevCode* __restrict__ codes, uint32_t* __restrict__ trellis,
                               uint32_t slot, SlotDesc desc, SlotDesc* __restrict__ slots) {
@@ -1435,7 +1500,22 @@ int launch_step_fast(const StepArgs& a, const Geometry& g, const DevCode* codes,
     return (int)hipGetLastError();
   }
   switch (g.L) {
+#if LVA_ACS_KERNEL
+    case 1: {
+      dim3 grid(g.N / TS, a.band_max, a.nslots), block(4 * TS);
+      switch (g.P) {
+        case 1: hipLaunchKernelGGL((lva_step_acs<1>), grid, block, 0, st, a, g, codes, trellis); break;
+        case 2: hipLaunchKernelGGL((lva_step_acs<2>), grid, block, 0, st, a, g, codes, trellis); break;
+        case 3: hipLaunchKernelGGL((lva_step_acs<3>), grid, block, 0, st, a, g, codes, trellis); break;
+        case 4: hipLaunchKernelGGL((lva_step_acs<4>), grid, block, 0, st, a, g, codes, trellis); break;
+        default: return (int)hipErrorInvalidValue;
+      }
+      e = (int)hipGetLastError();
+      break;
+    }
+#else
     case 1: e = launch_fast_p<1>(a, g, codes, trellis, hdr, items, st); break;
+#endif
     case 2: e = launch_fast_p<2>(a, g, codes, trellis, hdr, items, st); break;
     case 4: e = launch_fast_p<4>(a, g, codes, trellis, hdr, items, st); break;
     case 8: e = launch_fast_p<8>(a, g, codes, trellis, hdr, items, st); break;
@@ -1448,6 +1528,12 @@ int launch_step_fast(const StepArgs& a, const Geometry& g, const DevCode* codes,
     e = (int)hipGetLastError();
   }
   return e;
+}
+
+int launch_prepare_step(const StepArgs& a, SlotStep* steps, void* stream) {
+  if (a.nslots == 0) return 0;
+  hipLaunchKernelGGL(lva_prepare_step, dim3((a.nslots + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, steps);
+  return (int)hipGetLastError();
 }
 
 int launch_init_slot(const Geometry& g, const DevCode* codes, uint32_t* trellis, uint32_t slot, const SlotDesc& desc,
