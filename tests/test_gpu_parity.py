@@ -181,6 +181,6 @@ def test_hundreds_of_slots(oracle, L):
 
 
 def test_default_slot_count_grows_for_small_trellises():
-    for m, r, ml, want in ((6, 1, 60, 1024), (8, 1, 100, 256), (11, 1, 40, 32)):
+    for m, r, ml, want in ((6, 1, 60, 1024), (8, 1, 100, 256), (11, 1, 40, 64)):
         with pkg.Decoder(m, r, ml, list_size=2, max_deviation=20) as dec:
             assert dec.profile()["slots"] == want
