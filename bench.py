@@ -8,7 +8,7 @@ reverse-complement reads mixed.  It replaces the per-read loop of the reference'
 generate_decoded_lists.py:50-98 (one decoder subprocess per read).
 
 One "step" = one call of the hot path's C-ABI entry lva_decode_batch on one batch of host-resident
-synthetic reads per GPU (--reads-per-step, default 4x the decoder's read slots, so slots are refilled
+synthetic reads per GPU (--reads-per-step, default 2x the decoder's read slots, so slots are refilled
 inside the timed region); consecutive steps take consecutive batches out of a pool of --pool distinct
 reads per GPU (default 512).  `--resident` keeps the posteriors in HBM instead (lva_decode_batch_device).
 
@@ -43,7 +43,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads-per-step", type=int, default=0, help="reads per GPU per step (0 = 4 x read slots)")
+    ap.add_argument("--reads-per-step", type=int, default=0, help="reads per GPU per step (0 = 2 x read slots)")
     ap.add_argument("--pool", type=int, default=512, help="distinct synthetic reads per GPU the steps cycle through")
     ap.add_argument("--total-reads", type=int, default=0, help="strong scaling: reads per step over ALL GPUs")
     ap.add_argument("--resident", action="store_true", help="posteriors resident in HBM before the timed region")
@@ -138,7 +138,7 @@ def main():
         pool_idx = [int(i) for i in mine]
         nbatch = 1
     else:
-        per_step = a.reads_per_step or 4 * slots
+        per_step = a.reads_per_step or 2 * slots
         nbatch = max(1, -(-max(a.pool, 1) // per_step))     # batches in the pool
         pool_idx = [rank * nbatch * per_step + i for i in range(nbatch * per_step)]
         shards = [np.arange(r * per_step, (r + 1) * per_step, dtype=np.int64) for r in range(world)]
