@@ -1,9 +1,11 @@
 #!/bin/bash
 # FETCH_SIZE / WRITE_SIZE of the dominant kernel on the benchmark shape, separate --pmc passes (MI355X_MICROARCH.md, HBM):
-# one step of 128 reads through 32 slots (2034 launches), no per-launch events.   bash scripts/pmc_r2.sh [extra bench flags]
+# one step of 128 reads through 32 slots (2035 launches), no per-launch events.   bash scripts/pmc_r2.sh [extra bench flags]
+# (32 slots on purpose: with the default 64 slots the WRITE_SIZE pass did not come back from rocprofv3 within 15 minutes,
+#  twice; the FETCH_SIZE pass did: 5.20 GB raw per launch = twice the 32-slot figure, as expected)
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
-B="--steps 1 --warmup 0 --no-cpu-baseline --no-launch-events $*"
+B="--steps 1 --warmup 0 --slots 32 --reads-per-step 128 --no-cpu-baseline --no-launch-events $*"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/r2_pmc_$c
   timeout 900 rocprofv3 --pmc $c --output-format csv -d gpurun_out/r2_pmc_$c -- python3 bench.py $B > gpurun_out/r2_pmc_$c.log 2>&1 || echo "$c failed"
