@@ -747,6 +747,60 @@ template <int W> __device__ __forceinline__ void push_bits(uint32_t (&m)[W], uin
   }
 }
 
+// Output phase of fast_merge for list entries [l_begin, l_end): gather the surviving messages from HBM, shift in the new
+// bits, store coalesced (:771-774, :780); every fingerprint match filed under an entry must be the same message --
+// false = a collision, the exact path redoes the target.
+template <int LL, int P>
+__device__ __forceinline__ bool fast_output(const Geometry& g, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur, uint32_t k,
+                                            uint32_t c, uint32_t cp, uint32_t own, uint32_t src, uint32_t sh, uint32_t nb,
+                                            uint32_t np_dst, uint32_t np_src, unsigned long long asrc, unsigned long long rej0,
+                                            unsigned long long rej1, uint32_t lc, int l_begin, int l_end) {
+  const uint32_t N = g.N, sBlk = g.sBlk, sCrf = mul24(sBlk, LL), pw = 2 * g.N;
+  bool good = true;
+  constexpr int GB = LL >= 4 ? 4 : LL;       // entries whose loads are in flight together (8: 86 VGPRs, slower)
+#pragma unroll
+  for (int l0 = 0; l0 < LL; l0 += GB) {
+    if (l0 < l_begin || l0 >= l_end) continue;
+    uint32_t m[GB][2 * P];
+#pragma unroll
+    for (int u = 0; u < GB; ++u) {
+      const int l = l0 + u;
+      if ((uint32_t)l < lc) {
+        const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu;
+        const uint32_t i = a8 >> 3, j = a8 & 7u;
+        const uint32_t from = i == 0 ? own + mul24(j, sBlk) : src + mul24(list_crf(k, i), sCrf) + mul24(j, sBlk);
+        load_msg<P>(prev + from + pw, N, i == 0 ? c : cp, i == 0 ? np_dst : np_src, m[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < GB; ++u) {
+      const int l = l0 + u;
+      if ((uint32_t)l < lc) {
+        const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu;
+        push_bits<2 * P>(m[u], (a8 >> 3) == 0 ? 0u : sh, nb);
+        store_msg<P>(cur + own + l * sBlk + pw, N, c, np_dst, m[u]);
+        const uint32_t r0 = (uint32_t)(rej0 >> (7 * l)) & 0x7Fu;
+        if (r0) {
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const uint32_t rec = s2 ? (uint32_t)(rej1 >> (7 * l)) & 0x7Fu : r0;
+            if (rec & 0x40u) {
+              const uint32_t ri = (rec >> 3) & 7u, rj = rec & 7u;
+              const uint32_t rfrom = ri == 0 ? own + mul24(rj, sBlk) : src + mul24(list_crf(k, ri), sCrf) + mul24(rj, sBlk);
+              uint32_t qm[2 * P];
+              load_msg<P>(prev + rfrom + pw, N, ri == 0 ? c : cp, ri == 0 ? np_dst : np_src, qm);
+              push_bits<2 * P>(qm, ri == 0 ? 0u : sh, nb);
+#pragma unroll
+              for (int w = 0; w < 2 * P; ++w) good &= (qm[w] == m[u][w]);
+            }
+          }
+        }
+      }
+    }
+  }
+  return good;
+}
+
 // One target state on the fast path.  NL = 8 (flip target) or 2 (flop target).
 // s_src: LDS image [crf 8][LL][64] of (score, fingerprint) pairs of the source conv states.
 // Returns 0, or the reason (1 tie, 2 non-finite, 3 too many matches, 4 collision) why the
@@ -757,7 +811,7 @@ __device__ __forceinline__ int fast_merge(const Geometry& g, const uint32_t* __r
                                            uint32_t sc, uint32_t own, uint32_t src, uint32_t okmask, uint32_t sh,
                                            uint32_t nb, uint32_t fpc, uint32_t np_dst, uint32_t np_src) {
   const float NEG = -INFINITY;
-  const uint32_t N = g.N, sBlk = g.sBlk, sCrf = mul24(sBlk, LL), pw = 2 * g.N;   // pw: the SH plane that precedes an entry's message
+  const uint32_t sBlk = g.sBlk;
   const uint32_t row = k >= 4 ? 4u : k;
   const uint32_t own_c = own + 2 * c;                    // + l*sBlk: SH of own entry l
   int why = 0;
@@ -873,51 +927,7 @@ __device__ __forceinline__ int fast_merge(const Geometry& g, const uint32_t* __r
   for (int l = 0; l < LL; ++l)
     if ((uint32_t)l >= lc) *reinterpret_cast<uint2*>(cur + own_c + l * sBlk) = make_uint2(kNegInfBits, 0u);
 
-  // surviving messages: gather from HBM, shift in the new bits, store coalesced (:771-774, :780);
-  // every fingerprint match filed under the entry must be the same message, else the exact
-  // path redoes the target
-  bool good = true;
-  constexpr int GB = LL >= 4 ? 4 : LL;       // entries whose loads are in flight together (8: 86 VGPRs, slower)
-#pragma unroll
-  for (int l0 = 0; l0 < LL; l0 += GB) {
-    uint32_t m[GB][2 * P];
-#pragma unroll
-    for (int u = 0; u < GB; ++u) {
-      const int l = l0 + u;
-      if ((uint32_t)l < lc) {
-        const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu;
-        const uint32_t i = a8 >> 3, j = a8 & 7u;
-        const uint32_t from = i == 0 ? own + mul24(j, sBlk) : src + mul24(list_crf(k, i), sCrf) + mul24(j, sBlk);
-        load_msg<P>(prev + from + pw, N, i == 0 ? c : cp, i == 0 ? np_dst : np_src, m[u]);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < GB; ++u) {
-      const int l = l0 + u;
-      if ((uint32_t)l < lc) {
-        const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu;
-        push_bits<2 * P>(m[u], (a8 >> 3) == 0 ? 0u : sh, nb);
-        store_msg<P>(cur + own + l * sBlk + pw, N, c, np_dst, m[u]);
-        const uint32_t r0 = (uint32_t)(rej0 >> (7 * l)) & 0x7Fu;
-        if (r0) {
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            const uint32_t rec = s2 ? (uint32_t)(rej1 >> (7 * l)) & 0x7Fu : r0;
-            if (rec & 0x40u) {
-              const uint32_t ri = (rec >> 3) & 7u, rj = rec & 7u;
-              const uint32_t rfrom = ri == 0 ? own + mul24(rj, sBlk) : src + mul24(list_crf(k, ri), sCrf) + mul24(rj, sBlk);
-              uint32_t qm[2 * P];
-              load_msg<P>(prev + rfrom + pw, N, ri == 0 ? c : cp, ri == 0 ? np_dst : np_src, qm);
-              push_bits<2 * P>(qm, ri == 0 ? 0u : sh, nb);
-#pragma unroll
-              for (int w = 0; w < 2 * P; ++w) good &= (qm[w] == m[u][w]);
-            }
-          }
-        }
-      }
-    }
-  }
-  return good ? 0 : 4;
+  return fast_output<LL, P>(g, prev, cur, k, c, cp, own, src, sh, nb, np_dst, np_src, asrc, rej0, rej1, lc, 0, LL) ? 0 : 4;
 }
 
 // L == 1: plain add-compare-select, first maximum wins (:715-742).  No heap, no ties issue.
