@@ -210,8 +210,12 @@ int lva_decoder_create(const lva_config* cfg, lva_decoder** out) {
   if (c.msg_len > 255 || c.msg_len + (uint32_t)c.mem_conv > 256) { delete d; return LVA_ERR_MSG_TOO_LONG; }
   if ((uint64_t)c.npos * kCrf * c.nconv >= ((uint64_t)1 << 32)) { delete d; return LVA_ERR_TOO_MANY_STATES; }
   d->max_dev = cfg->max_deviation == LVA_MAX_DEVIATION_DEFAULT ? c.msg_len + (uint32_t)c.mem_conv + 1 : cfg->max_deviation;
-  const uint64_t ring = std::min<uint64_t>(c.npos, 2ull * d->max_dev + 1);
-  d->g = make_geometry(c.nconv, cfg->list_size, c.msg_bits(), (uint32_t)std::max<uint64_t>(ring, 1));
+  // kernel mode 4 ("lazy", list sizes 2, 4, 8): messages are materialised every second time step and carried as one-byte
+  // back-pointers in between; two-hop chains reach one position further below the band, hence one more ring position
+  const bool lazy = cfg->kernel == 4;
+  if (lazy && !(cfg->list_size == 2 || cfg->list_size == 4 || cfg->list_size == 8)) { delete d; return LVA_ERR_UNSUPPORTED; }
+  const uint64_t ring = std::min<uint64_t>(c.npos, 2ull * d->max_dev + (lazy ? 2 : 1));
+  d->g = make_geometry(c.nconv, cfg->list_size, c.msg_bits(), (uint32_t)std::max<uint64_t>(ring, 1), lazy ? 1u : 0u);
   if (d->g.sPar >= ((uint64_t)1 << 32)) { delete d; return LVA_ERR_TOO_MANY_STATES; }
 
   int ndev = 0;
@@ -252,7 +256,8 @@ int lva_decoder_create(const lva_config* cfg, lva_decoder** out) {
   if (cfg->kernel == 2 && !fast_ok) return fail(LVA_ERR_UNSUPPORTED);
   // 1 = exact (one thread per target), 2 = fast + fix-up, 3 = wavefront per target (lists of 9..64 entries)
   if (cfg->kernel == 3 && !wave_kernel_available(d->g)) return fail(LVA_ERR_UNSUPPORTED);
-  d->kernel = cfg->kernel == 1 ? 1 : cfg->kernel == 3 ? 3 : (fast_ok ? 2 : (wave_kernel_available(d->g) ? 3 : 1));
+  d->kernel = cfg->kernel == 1 ? 1 : cfg->kernel == 3 ? 3 : cfg->kernel == 4 ? 4 : (fast_ok ? 2 : (wave_kernel_available(d->g) ? 3 : 1));
+  if (d->kernel == 4 && (!fast_ok || c.nconv < 64)) return fail(LVA_ERR_UNSUPPORTED);
   d->prof.kernel = d->kernel;
   if (const char* cap = std::getenv("LVA_WORK_CAP")) {       // tests: force the work-list overflow path
     const long v = std::atol(cap);
@@ -364,10 +369,24 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
       band_at[(size_t)r] = at;
       const Code& c = d->code[rc_flags && rc_flags[r] ? 1 : 0];
       const uint32_t nb = (uint32_t)len[r];
+      // lazy mode: when was each position's row of either parity buffer last written?  Step t reads the buffer written
+      // by steps of t-1's parity; only the row of position lo-1 can be older than t-1 ("stale"), and at odd t
+      // its entries' messages live in the message buffer of the (even) step that wrote it
+      std::vector<int64_t> last_w[2];
+      if (d->g.lazy) { last_w[0].assign(c.npos + 1, -1); last_w[1].assign(c.npos + 1, -1); if (c.npos) last_w[1][0] = -1; }
       for (uint32_t t = 0; t < nb; ++t) {
         uint32_t lo, hi;
         c.band(t, nb, d->max_dev, &lo, &hi);
-        band[at + t] = lo | (hi << 16);
+        uint32_t w = lo | (hi << 16);
+        if (d->g.lazy) {
+          const int pc = (int)((t + 1) & 1u);                // parity class of the steps that wrote step t's "prev" buffer: t-1
+          if (t >= 1 && lo >= 1) {
+            const int64_t lw = last_w[pc][lo - 1];
+            if (lw >= 0 && lw != (int64_t)t - 1) w |= 1u << 30 | (uint32_t)((lw >> 1) & 1) << 31;
+          }
+          for (uint32_t p = lo; p < hi; ++p) last_w[t & 1u][p] = t;
+        }
+        band[at + t] = w;
       }
       at += nb;
     }
@@ -438,14 +457,14 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
     }
     first_step = false;
     {
-      const int e = d->kernel == 2
+      const int e = d->kernel == 2 || d->kernel == 4
                         ? launch_step_fast(a, g, d->d_codes, d->d_trellis, d->d_work, reinterpret_cast<uint32_t*>(d->d_work + 1), d->stream, e1)
                         : d->kernel == 3 ? launch_step_wave(a, g, d->d_codes, d->d_trellis, d->stream)
                                          : launch_step_exact(a, g, d->d_codes, d->d_trellis, d->stream);
       if (e) { g_hip_error = hipGetErrorString((hipError_t)e); return LVA_ERR_HIP; }
     }
     if (e2) {
-      if (d->kernel != 2) HIP_TRY(hipEventRecord(e1, d->stream));
+      if (d->kernel != 2 && d->kernel != 4) HIP_TRY(hipEventRecord(e1, d->stream));
       HIP_TRY(hipEventRecord(e2, d->stream));
     }
     ++d->launch_no;
@@ -457,8 +476,8 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
       const int32_t r = slot[s].read;
       const uint32_t nb = (uint32_t)len[r], orient = rc_flags && rc_flags[r] ? 1u : 0u;
       const uint32_t last = band[band_at[(size_t)r] + nb - 1];
-      if ((last & 0xFFFFu) <= npos - 1 && npos - 1 < (last >> 16)) {   // otherwise the final state was never written: empty list
-        GatherArgs ga{(uint32_t)s, (uint32_t)(nb & 1u), orient, (uint32_t)r};
+      if ((last & 0xFFFFu) <= npos - 1 && npos - 1 < ((last >> 16) & 0x3FFFu)) {   // otherwise the final state was never written: empty list
+        GatherArgs ga{(uint32_t)s, (uint32_t)(nb & 1u), orient, (uint32_t)r, nb};
         const int e = launch_gather_final(g, d->d_codes, d->d_trellis, ga, d->d_results, d->stream);
         if (e) { g_hip_error = hipGetErrorString((hipError_t)e); return LVA_ERR_HIP; }
         gathered[(size_t)r] = 1;
@@ -475,6 +494,7 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
   HIP_TRY(hipEventRecord(d->ev_total1, d->stream));
   HIP_TRY(hipStreamSynchronize(d->stream));
   drain.armed = false;
+  if (d->kernel == 4 && h1.pad) { g_hip_error = "lazy mode: the exact path's work list overflowed"; return LVA_ERR_UNSUPPORTED; }
   d->prof.fixup_states = h1.total;
   for (int i = 0; i < 4; ++i) d->prof.fixup_reason[i] = h1.reason[i];
   float ms = 0;

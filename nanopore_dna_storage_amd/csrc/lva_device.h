@@ -49,8 +49,8 @@ struct DevCode {                 // one per orientation (0 = forward, 1 = revers
 // whole schedule of a batch without per-launch argument tables, for any number of slots.
 struct SlotDesc {
   const float* post;             // block 0 of the read's posterior matrix (device)
-  const uint32_t* band;          // [nblk] lo | hi << 16: the band of every time step (:677-679), evaluated on
-                                 // the host exactly as the reference binary does (Code::band)
+  const uint32_t* band;          // [nblk] lo | hi << 16 (| lazy-mode flags << 30): the band of every time step (:677-679),
+                                 // evaluated on the host exactly as the reference binary does (Code::band)
   uint32_t nblk, orient;
   uint32_t start;                // launch number of the read's time step 0
   uint32_t pad;
@@ -64,12 +64,15 @@ struct SlotStep {                // what one read slot does in one trellis-step 
   uint32_t lo, hi;               // band of step t
   uint32_t prev_hi;              // band end of step t-1 (1 at t = 0: only position 0 is initialised)
   uint32_t orient;
+  uint32_t flags;                // lazy mode (kernel 4): bit 0 = the row of position lo-1 in the previous buffer is stale (written
+                                 // before step t-1); bit 1 = which message buffer the messages of its entries live in
+  uint32_t pad;
 };
 
 struct StepArgs {
   const SlotDesc* slots;         // device
   const SlotStep* steps;         // device, [nslots]: this launch's SlotStep of every slot, written by lva_prepare_step
-                                 // right before the launch (t = 0xFFFFFFFF: the slot takes no part) -- one 32-byte record per
+                                 // right before the launch (t = 0xFFFFFFFF: the slot takes no part) -- one 40-byte record per
                                  // workgroup instead of the dependent chain  descriptor -> band[t], band[t-1]
   uint32_t nslots;               // slots in use by this batch (grid z)
   uint32_t band_max;             // positions per band at most (grid y)
@@ -79,15 +82,17 @@ struct StepArgs {
 
 struct Geometry {                // strides in 32-bit words
   uint32_t N, L, W, F, R, P;
-  uint32_t sBlk;                 // one (ring, crf, list entry) block = N*F
+  uint32_t sBlk;                 // one (ring, crf, list entry) block = N*F (+ N/4 words of back-pointer bytes when lazy)
+  uint32_t lazy;                 // kernel mode 4: messages are materialised every second time step (lva_kernels.hip, "lazy")
   uint64_t sCrf, sRing, sPar, sSlot;
 };
 
-inline Geometry make_geometry(uint32_t N, uint32_t L, uint32_t msg_bits, uint32_t R) {
+inline Geometry make_geometry(uint32_t N, uint32_t L, uint32_t msg_bits, uint32_t R, uint32_t lazy = 0) {
   Geometry g;
   g.N = N; g.L = L; g.P = (msg_bits + 63) / 64; if (g.P == 0) g.P = 1;
   g.W = 2 * g.P; g.F = g.W + 2; g.R = R;
-  g.sBlk = N * g.F;
+  g.lazy = lazy;
+  g.sBlk = N * g.F + (lazy ? N / 4 : 0);
   g.sCrf = (uint64_t)g.sBlk * L; g.sRing = g.sCrf * 8;
   g.sPar = g.sRing * R; g.sSlot = g.sPar * 2;
   return g;
@@ -107,6 +112,7 @@ struct WorkHdr {
 // final-state gather: result record per read = [crf 8][list L][field F] words
 struct GatherArgs {
   uint32_t slot, parity, orient, read;
+  uint32_t nblk;                 // blocks of the read (lazy mode: whether the last step stored messages or back-pointers)
 };
 
 }  // namespace lva

@@ -805,11 +805,14 @@ __device__ __forceinline__ bool fast_output(const Geometry& g, const uint32_t* _
 // s_src: LDS image [crf 8][LL][64] of (score, fingerprint) pairs of the source conv states.
 // Returns 0, or the reason (1 tie, 2 non-finite, 3 too many matches, 4 collision) why the
 // target must be redone by the exact path.
-template <int LL, int P, int NL>
-__device__ __forceinline__ int fast_merge(const Geometry& g, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur,
-                                           const uint2* s_src, const float* s_post, uint32_t k, uint32_t c, uint32_t cp,
-                                           uint32_t sc, uint32_t own, uint32_t src, uint32_t okmask, uint32_t sh,
-                                           uint32_t nb, uint32_t fpc, uint32_t np_dst, uint32_t np_src) {
+// The merge proper: decides the new list (scores and fingerprints are stored as it goes) and reports where every accepted
+// entry came from (asrc) and which fingerprint matches still have to be verified on the full message (rej0 / rej1).
+template <int LL, int NL>
+__device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur,
+                                                const uint2* s_src, const float* s_post, uint32_t k, uint32_t c,
+                                                uint32_t sc, uint32_t own, uint32_t okmask, uint32_t fpc,
+                                                unsigned long long* o_asrc, unsigned long long* o_rej0, unsigned long long* o_rej1,
+                                                uint32_t* o_lc) {
   const float NEG = -INFINITY;
   const uint32_t sBlk = g.sBlk;
   const uint32_t row = k >= 4 ? 4u : k;
@@ -926,7 +929,19 @@ __device__ __forceinline__ int fast_merge(const Geometry& g, const uint32_t* __r
 #pragma unroll
   for (int l = 0; l < LL; ++l)
     if ((uint32_t)l >= lc) *reinterpret_cast<uint2*>(cur + own_c + l * sBlk) = make_uint2(kNegInfBits, 0u);
+  *o_asrc = asrc; *o_rej0 = rej0; *o_rej1 = rej1; *o_lc = lc;
+  return 0;
+}
 
+template <int LL, int P, int NL>
+__device__ __forceinline__ int fast_merge(const Geometry& g, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur,
+                                           const uint2* s_src, const float* s_post, uint32_t k, uint32_t c, uint32_t cp,
+                                           uint32_t sc, uint32_t own, uint32_t src, uint32_t okmask, uint32_t sh,
+                                           uint32_t nb, uint32_t fpc, uint32_t np_dst, uint32_t np_src) {
+  unsigned long long asrc, rej0, rej1;
+  uint32_t lc;
+  const int why = fast_merge_core<LL, NL>(g, prev, cur, s_src, s_post, k, c, sc, own, okmask, fpc, &asrc, &rej0, &rej1, &lc);
+  if (why) return why;
   return fast_output<LL, P>(g, prev, cur, k, c, cp, own, src, sh, nb, np_dst, np_src, asrc, rej0, rej1, lc, 0, LL) ? 0 : 4;
 }
 
@@ -1080,6 +1095,371 @@ __global__ __launch_bounds__(8 * TS) void lva_step_fast(StepArgs args, Geometry 
     const uint32_t idx = atomicAdd(&hdr->count[args.step_parity], 1u);
     if (idx < hdr->cap) items[idx] = make_item(cd.m, blockIdx.z, blockIdx.y, k, c);
     else hdr->overflow[args.step_parity] = 1u;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Lazy messages (kernel mode 4, list sizes 2 / 4 / 8).
+//
+// The reference carries the whole message with every list entry through every time step (:771-774).  Scores and
+// fingerprints decide everything the merge does; the message itself is only needed to confirm a fingerprint match and
+// at the very end.  So here the message is MATERIALISED EVERY SECOND STEP: a step with even t ("anchor") stores messages
+// as lva_step_fast does; a step with odd t stores one byte per accepted entry instead -- where the entry came from in
+// step t-1's lists (list i, index j) and which message buffer holds that entry's message.  The next anchor step follows
+// two hops (its candidate -> step t-1's entry -> that entry's byte -> step t-2's entry), gathers the message there and
+// shifts in the bits of both moves.  Odd steps move no messages at all (except to confirm fingerprint matches): about a
+// quarter of the bytes of a step pair disappears.
+//   * two message buffers (the message planes of the two parity buffers, otherwise unused at odd steps): anchor step t
+//     writes buffer (t >> 1) & 1 and reads, through the bytes, whichever buffer the byte names -- never rows it writes;
+//   * the stale row (position lo-1 read with contents older than t-1) keeps working: its entries' messages
+//     are where they were written (rows below the band are never overwritten); the host tells odd steps which buffer
+//     that is (SlotStep.flags), anchor steps read it from the byte; two hops reach position lo-2, so the ring has one
+//     more position (R = 2 max_deviation + 2);
+//   * the exact path (lva_step_fixup_lazy, one wavefront per target) resolves messages the same way.
+// ---------------------------------------------------------------------------------------
+namespace {
+
+struct LazyCtx {
+  const uint32_t* M[2];          // the two parity buffers of the slot (message planes = message buffers 0 and 1)
+  const uint8_t* bp_prev;        // back-pointer bytes of the previous step's buffer (anchor steps)
+  uint32_t N, sBlk, sCrf, pw, m;
+  uint32_t c, cp, k, own, src, src2;   // target conv, source conv, target crf; word offsets of (ring(pos),k), ring(pos-1), ring(pos-2)
+  uint32_t sh_p, nb_p;           // the move into (pos, c)
+  uint32_t sh_q, nb_q, pk1;      // the move into (pos-1, cp); predecessors of cp there (predtab nibbles)
+  uint32_t np_p, np_p1, np_p2;   // message planes in use at pos, pos-1, pos-2
+  uint32_t t, fb, stale_pos1, stale_mb;  // time step; message buffer of fresh step t-1 entries; sources at pos-1 stale? its buffer
+};
+
+__device__ __forceinline__ uint32_t bp_byte_index(const Geometry& g, uint32_t list, uint32_t j, uint32_t conv) {
+  return (list + j * g.sBlk + g.N * g.F) * 4u + conv;        // byte index into a parity buffer
+}
+
+// message buffer that holds the message of step t-1's entry of list i (odd steps)
+__device__ __forceinline__ uint32_t lazy_mbuf(const LazyCtx& x, uint32_t i) { return (i != 0 && x.stale_pos1) ? x.stale_mb : x.fb; }
+
+// Message of candidate (list i, index j) of the previous step AS IT WOULD STAND IN THE TARGET (all moves applied).
+// bp1 = the candidate's own back-pointer byte (anchor steps; ignored at odd steps).
+template <int P>
+__device__ __forceinline__ void lazy_message(const LazyCtx& x, uint32_t i, uint32_t j, uint32_t bp1, uint32_t (&mw)[2 * P]) {
+  const uint32_t kk = i == 0 ? x.k : list_crf(x.k, i);
+  if (x.t & 1u) {                                            // odd step: step t-1's entries carry their messages
+    const uint32_t lst = i == 0 ? x.own : x.src + mul24(kk, x.sCrf);
+    load_msg<P>(x.M[lazy_mbuf(x, i)] + lst + mul24(j, x.sBlk) + x.pw, x.N, i == 0 ? x.c : x.cp, i == 0 ? x.np_p : x.np_p1, mw);
+    push_bits<2 * P>(mw, i == 0 ? 0u : x.sh_p, x.nb_p);
+    return;
+  }
+  if (x.t == 0) {                                            // the initial entries: empty message
+#pragma unroll
+    for (int w = 0; w < 2 * P; ++w) mw[w] = 0;
+    push_bits<2 * P>(mw, i == 0 ? 0u : x.sh_p, x.nb_p);
+    return;
+  }
+  const uint32_t i1 = (bp1 >> 3) & 7u, j1 = bp1 & 7u, mb = (bp1 >> 6) & 1u;
+  uint32_t lst, conv, np, s1 = 0, n1 = 0;
+  if (i == 0) {                                              // candidate = own state one step ago
+    if (i1 == 0) { lst = x.own; conv = x.c; np = x.np_p; }
+    else { lst = x.src + mul24(list_crf(x.k, i1), x.sCrf); conv = x.cp; np = x.np_p1; }
+  } else {                                                   // candidate = state (pos-1, cp, kk) one step ago
+    if (i1 == 0) { lst = x.src + mul24(kk, x.sCrf); conv = x.cp; np = x.np_p1; }
+    else {
+      const uint32_t y1 = (x.pk1 >> (4 * (kk & 3u))) & 7u;
+      conv = ((x.cp << x.sh_q) | y1) & (x.N - 1u);
+      lst = x.src2 + mul24(list_crf(kk, i1), x.sCrf); np = x.np_p2;
+      s1 = x.sh_q; n1 = x.nb_q;
+    }
+  }
+  load_msg<P>(x.M[mb] + lst + mul24(j1, x.sBlk) + x.pw, x.N, conv, np, mw);
+  push_bits<2 * P>(mw, s1, n1);
+  push_bits<2 * P>(mw, (i != 0 || i1 != 0) ? x.sh_p : 0u, x.nb_p);
+}
+
+__device__ __forceinline__ void lazy_ctx(const DevCode& cd, const Geometry& g, const SlotStep& ss, const uint32_t* slot_base, uint32_t pos,
+                                         uint32_t c, uint32_t cp, uint32_t k, uint32_t own, LazyCtx* x) {
+  x->M[0] = slot_base; x->M[1] = slot_base + g.sPar;
+  x->bp_prev = reinterpret_cast<const uint8_t*>(slot_base + (uint64_t)(ss.t & 1u) * g.sPar);
+  x->N = g.N; x->sBlk = g.sBlk; x->sCrf = (uint32_t)g.sCrf; x->pw = 2 * g.N; x->m = cd.m;
+  x->c = c; x->cp = cp; x->k = k; x->own = own;
+  x->src = (uint32_t)((uint64_t)((pos + g.R - 1) % g.R) * 8 * g.sCrf);
+  x->src2 = (uint32_t)((uint64_t)((pos + g.R - 2) % g.R) * 8 * g.sCrf);
+  const uint32_t Tp = cd.ptype[pos];
+  x->sh_p = Tp == 0 ? 1u : 2u;
+  x->nb_p = x->sh_p == 1 ? (c >> (cd.m - 1)) : (2 * ((c >> (cd.m - 2)) & 1u) + (c >> (cd.m - 1)));
+  const uint32_t Tq = pos >= 1 ? cd.ptype[pos - 1] : 0u;
+  x->sh_q = Tq == 0 ? 1u : 2u;
+  x->nb_q = x->sh_q == 1 ? (cp >> (cd.m - 1)) : (2 * ((cp >> (cd.m - 2)) & 1u) + (cp >> (cd.m - 1)));
+  x->pk1 = pos >= 2 ? cd.predtab[Tq][cp] : 0u;
+  x->np_p = cd.npair[pos]; x->np_p1 = pos >= 1 ? cd.npair[pos - 1] : 1u; x->np_p2 = pos >= 2 ? cd.npair[pos - 2] : 1u;
+  x->t = ss.t; x->fb = ((ss.t - 1u) >> 1) & 1u;
+  x->stale_pos1 = (pos == ss.lo) && (ss.flags & 1u);
+  x->stale_mb = (ss.flags >> 1) & 1u;
+}
+
+// Output phase of one target on the lazy path.  false = a fingerprint match did not survive the comparison of the
+// full messages (collision): the exact path redoes the target.
+template <int LL, int P>
+__device__ __forceinline__ bool lazy_output(const Geometry& g, const LazyCtx& x, uint32_t* __restrict__ cur, uint32_t* __restrict__ mout,
+                                            const uint8_t* s_bp, uint32_t sc, unsigned long long asrc, unsigned long long rej0,
+                                            unsigned long long rej1, uint32_t lc) {
+  bool good = true;
+  const bool anchor = !(x.t & 1u);
+  // the candidate's own back-pointer byte (anchor steps): staged in LDS for source lists, in the previous buffer for the stay list
+  auto bp_of = [&](uint32_t i, uint32_t j) -> uint32_t {
+    if (!anchor || x.t == 0) return 0u;
+    if (i == 0) return x.bp_prev[bp_byte_index(g, x.own, j, x.c)];
+    return s_bp[(mul24(list_crf(x.k, i), LL) + j) * TS + sc];
+  };
+  uint8_t* bp_cur = reinterpret_cast<uint8_t*>(cur);
+#pragma unroll
+  for (int l = 0; l < LL; ++l) {
+    if ((uint32_t)l < lc) {
+      const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu;
+      const uint32_t i = a8 >> 3, j = a8 & 7u;
+      const uint32_t r0 = (uint32_t)(rej0 >> (7 * l)) & 0x7Fu;
+      uint32_t mw[2 * P];
+      if (anchor || r0) lazy_message<P>(x, i, j, bp_of(i, j), mw);
+      if (anchor) store_msg<P>(mout + x.own + l * x.sBlk + x.pw, x.N, x.c, x.np_p, mw);
+      else bp_cur[bp_byte_index(g, x.own, l, x.c)] = (uint8_t)(a8 | (lazy_mbuf(x, i) << 6));
+      if (r0) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const uint32_t rec = s2 ? (uint32_t)(rej1 >> (7 * l)) & 0x7Fu : r0;
+          if (rec & 0x40u) {
+            const uint32_t ri = (rec >> 3) & 7u, rj = rec & 7u;
+            uint32_t qm[2 * P];
+            lazy_message<P>(x, ri, rj, bp_of(ri, rj), qm);
+#pragma unroll
+            for (int w = 0; w < 2 * P; ++w) good &= (qm[w] == mw[w]);
+          }
+        }
+      }
+    }
+  }
+  return good;
+}
+
+}  // namespace
+
+// grid / block as lva_step_fast.
+template <int LL, int P>
+__global__ __launch_bounds__(8 * TS) void lva_step_lazy(StepArgs args, Geometry g, const DevCode* __restrict__ codes,
+                                                     uint32_t* __restrict__ trellis, WorkHdr* __restrict__ hdr,
+                                                     uint32_t* __restrict__ items) {
+  __shared__ uint2 s_src[8 * LL * TS];
+  __shared__ uint8_t s_bp[8 * LL * TS];
+  __shared__ float s_post[40];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+    hdr->count[args.step_parity ^ 1u] = 0;     // the other parity's list was consumed by the last fix-up
+    hdr->overflow[args.step_parity ^ 1u] = 0;
+  }
+  SlotStep ss;
+  if (!load_slot(args, blockIdx.z, &ss)) return;
+  const uint32_t pos = ss.lo + blockIdx.y;
+  if (pos >= ss.hi) return;
+  const DevCode& cd = codes[ss.orient];
+  const uint32_t N = cd.nconv, tid = threadIdx.x, tile = blockIdx.x;
+  uint32_t* slot_base = trellis + (uint64_t)ss.slot * g.sSlot;
+  const uint32_t* prev; uint32_t* cur;
+  slot_buffers(ss, g, trellis, &prev, &cur);
+  const bool anchor = !(ss.t & 1u);
+  uint32_t* mout = slot_base + (uint64_t)((ss.t >> 1) & 1u) * g.sPar;      // message buffer an anchor step writes
+
+  if (pos == 0) {                          // stay-only update of the 8 start states (:706-713); their message stays empty
+    if (tile == cd.init / TS && tid < 8) {
+      const uint32_t k = tid, c = cd.init;
+      const uint32_t own = (uint32_t)((uint64_t)k * g.sCrf), own_c = own + 2 * c;
+      const float s = u2f(prev[own_c]) + ss.post_row[(k >= 4 ? 4u : k) * 8 + k];
+      cur[own_c] = f2u(s);
+      cur[own_c + 1] = prev[own_c + 1];
+      if (anchor) { mout[own + 2 * N + 2 * c] = 0u; mout[own + 2 * N + 2 * c + 1] = 0u; }
+      else reinterpret_cast<uint8_t*>(cur)[bp_byte_index(g, own, 0, c)] = (uint8_t)((((ss.t - 1u) >> 1) & 1u) << 6);   // stay, entry 0
+      for (int l = 1; l < LL; ++l) cur[own_c + l * g.sBlk] = kNegInfBits;
+    }
+    return;
+  }
+
+  // ---- stage the (score, fingerprint) pairs of 64 source conv states (and, for an anchor step, their back-pointer bytes) ----
+  const uint32_t src = (uint32_t)((uint64_t)((pos - 1) % g.R) * 8 * g.sCrf);
+  for (uint32_t chunk = tid; chunk < 8u * LL * (TS / 2); chunk += 8u * TS) {
+    const uint32_t rowi = chunk / (TS / 2), lane2 = chunk % (TS / 2);       // rowi = crf * LL + l
+    const uint4 v = *reinterpret_cast<const uint4*>(prev + src + (uint64_t)rowi * g.sBlk + 2 * (tile * TS) + 4 * lane2);
+    *reinterpret_cast<uint4*>(&s_src[rowi * TS + 2 * lane2]) = v;
+  }
+  if (anchor && ss.t != 0) {
+    for (uint32_t chunk = tid; chunk < 8u * LL * (TS / 4); chunk += 8u * TS) {
+      const uint32_t rowi = chunk / (TS / 4), q4 = chunk % (TS / 4);
+      const uint32_t v = prev[src + (uint64_t)rowi * g.sBlk + N * g.F + (tile * TS) / 4 + q4];
+      *reinterpret_cast<uint32_t*>(&s_bp[rowi * TS + 4 * q4]) = v;
+    }
+  }
+  if (tid < 40) s_post[tid] = ss.post_row[tid];
+  __syncthreads();
+
+  TileTarget t;
+  if (!tile_target<TS>(cd, g, ss, pos, tile, tid, &t)) return;
+  unsigned long long asrc = 0, rej0 = 0, rej1 = 0;
+  uint32_t lc = 0;
+  int why = t.k < 4 ? fast_merge_core<LL, 8>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &rej1, &lc)
+                    : fast_merge_core<LL, 2>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &rej1, &lc);
+  if (!why) {
+    LazyCtx x;
+    lazy_ctx(cd, g, ss, slot_base, pos, t.c, t.cp, t.k, t.own, &x);
+    if (!lazy_output<LL, P>(g, x, cur, mout, s_bp, t.sc, asrc, rej0, rej1, lc)) why = 4;
+  }
+  if (why) {
+    atomicAdd(&hdr->reason[why - 1], 1ull);
+    const uint32_t idx = atomicAdd(&hdr->count[args.step_parity], 1u);
+    if (idx < hdr->cap) items[idx] = make_item(cd.m, blockIdx.z, blockIdx.y, t.k, t.c);
+    else hdr->overflow[args.step_parity] = 1u;
+  }
+}
+
+// exact path behind lva_step_lazy: one wavefront per queued target, the reference merge (:743-800) on lane-resident values
+// as fixup_small, messages resolved through lazy_message.
+template <int P>
+__global__ __launch_bounds__(256) void lva_step_fixup_lazy(StepArgs args, Geometry g, const DevCode* __restrict__ codes,
+                                                           uint32_t* __restrict__ trellis, WorkHdr* __restrict__ hdr,
+                                                           const uint32_t* __restrict__ items) {
+  const uint32_t par = args.step_parity;
+  const uint32_t n = hdr->count[par] < hdr->cap ? hdr->count[par] : hdr->cap;
+  if (hdr->overflow[par] != 0) {           // (no whole-step fallback on this path: reported to the host, which refuses the batch)
+    if (blockIdx.x == 0 && threadIdx.x == 0) hdr->pad = 1u;
+    return;
+  }
+  if (n == 0) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&hdr->total, (unsigned long long)n);
+  const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u, nwaves = gridDim.x * 4;
+  const uint32_t L = g.L, sBlk = g.sBlk, sCrf = (uint32_t)g.sCrf;
+  const float NEG = -INFINITY;
+  auto rdf = [](float v, uint32_t ln) -> float { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)ln)); };
+  auto rdu = [](uint32_t v, uint32_t ln) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)ln); };
+  auto wrf = [lane](float& v, uint32_t ln, float x) { v = lane == ln ? x : v; };
+  auto wru = [lane](uint32_t& v, uint32_t ln, uint32_t x) { v = lane == ln ? x : v; };
+  for (uint32_t idx = blockIdx.x * 4 + wv; idx < n; idx += nwaves) {
+    const uint32_t it = items[idx];
+    const uint32_t mm = codes[0].m;
+    SlotStep ss;
+    if (!load_slot(args, it >> (mm + 11), &ss)) continue;
+    const uint32_t pos = ss.lo + ((it >> (mm + 3)) & 0xFFu), k = (it >> mm) & 7u, c = it & ((1u << mm) - 1u);
+    const DevCode& cd = codes[ss.orient];
+    const uint32_t* prev; uint32_t* cur;
+    slot_buffers(ss, g, trellis, &prev, &cur);
+    uint32_t* slot_base = trellis + (uint64_t)ss.slot * g.sSlot;
+    uint32_t* mout = slot_base + (uint64_t)((ss.t >> 1) & 1u) * g.sPar;
+    Target tg;
+    if (!resolve_target(cd, g, ss, pos, c, k, &tg)) continue;   // (uniform per wavefront)
+    if (pos == 0) continue;
+    LazyCtx x;
+    lazy_ctx(cd, g, ss, slot_base, pos, tg.c, tg.cp, k, tg.own, &x);
+    const bool anchor = !(ss.t & 1u);
+    // 1. candidates: lane = list*8 + index
+    float cs = NEG; uint32_t cy = 0, cb = 0;
+    {
+      const uint32_t i = lane >> 3, j = lane & 7u;
+      if (i < tg.nlists && ((tg.okmask >> i) & 1u) && j < L) {
+        const uint32_t lst = i == 0 ? tg.own : tg.src + list_crf(k, i) * sCrf;
+        const uint2 v = *reinterpret_cast<const uint2*>(prev + lst + j * sBlk + 2 * (i == 0 ? tg.c : tg.cp));
+        cs = u2f(v.x); cy = i != 0 ? v.y ^ tg.fpc : v.y;
+        if (anchor && ss.t != 0) cb = x.bp_prev[bp_byte_index(g, lst, j, i == 0 ? tg.c : tg.cp)];
+      }
+    }
+    float addv = 0.0f;
+    if (lane < tg.nlists) addv = ss.post_row[tg.row * 8 + (lane == 0 ? k : list_crf(k, lane))];
+    // word w of the candidate message of entry (li, lj): every lane computes the whole message and picks its word
+    auto word_of = [&](uint32_t li, uint32_t lj, uint32_t w) -> uint32_t {
+      uint32_t mw[2 * P];
+      lazy_message<P>(x, li, lj, rdu(cb, li * 8 + lj), mw);
+      uint32_t v = 0;
+#pragma unroll
+      for (int u = 0; u < 2 * P; ++u) v = w == (uint32_t)u ? mw[u] : v;
+      return v;
+    };
+    float hs = NEG; uint32_t hx = 0;
+    float as = NEG; uint32_t ay = 0, ax = 0;
+    auto sift_up = [&](uint32_t hole, uint32_t top, float vs, uint32_t vx) {
+      while (hole > top) {
+        const uint32_t parent = (hole - 1) / 2;
+        const float ps = rdf(hs, parent);
+        if (!(ps < vs)) break;
+        wrf(hs, hole, ps); wru(hx, hole, rdu(hx, parent));
+        hole = parent;
+      }
+      wrf(hs, hole, vs); wru(hx, hole, vx);
+    };
+    auto adjust = [&](uint32_t hole, uint32_t len, float vs, uint32_t vx) {
+      const uint32_t top = hole;
+      uint32_t child = hole;
+      while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (rdf(hs, child) < rdf(hs, child - 1)) --child;
+        wrf(hs, hole, rdf(hs, child)); wru(hx, hole, rdu(hx, child));
+        hole = child;
+      }
+      if ((len & 1u) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        wrf(hs, hole, rdf(hs, child - 1)); wru(hx, hole, rdu(hx, child - 1));
+        hole = child - 1;
+      }
+      sift_up(hole, top, vs, vx);
+    };
+    uint32_t hn = 0;
+    for (uint32_t i = 0; i < tg.nlists; ++i) {                         // :750-761
+      const float head = rdf(cs, i * 8);
+      if (head != NEG) { wrf(hs, hn, head + rdf(addv, i)); wru(hx, hn, i << 16); ++hn; }
+    }
+    if (hn >= 2)                                                       // std::make_heap :762
+      for (uint32_t parent = (hn - 2) / 2;; --parent) {
+        adjust(parent, hn, rdf(hs, parent), rdu(hx, parent));
+        if (parent == 0) break;
+      }
+    uint32_t l = 0;
+    const uint32_t Wd = 2 * tg.np_dst;
+    while (hn > 0 && l < L) {                                          // :764
+      const float ts = rdf(hs, 0); const uint32_t tx = rdu(hx, 0);
+      if (hn > 1) adjust(0, hn - 1, rdf(hs, hn - 1), rdu(hx, hn - 1));
+      --hn;
+      const uint32_t i = tx >> 16, j = tx & 0xFFFFu;
+      const uint32_t ch = rdu(cy, i * 8 + j);
+      bool dup = false;                                                // :778-779
+      unsigned long long match = __ballot(lane < l && ay == ch);
+      while (match && !dup) {
+        const uint32_t a = (uint32_t)__builtin_ctzll(match);
+        match &= match - 1;
+        const uint32_t asrc = rdu(ax, a);
+        uint32_t diff = 0;
+        const uint32_t wa = word_of(i, j, lane < Wd ? lane : 0u), wb2 = word_of(asrc >> 16, asrc & 0xFFFFu, lane < Wd ? lane : 0u);
+        if (lane < Wd) diff = wa ^ wb2;
+        dup = __ballot(diff != 0) == 0ull;
+      }
+      if (!dup) { wrf(as, l, ts); wru(ay, l, ch); wru(ax, l, tx); ++l; }
+      if (j == L - 1) continue;
+      const float nxt = rdf(cs, i * 8 + j + 1);
+      if (nxt != NEG) {
+        sift_up(hn, 0, nxt + rdf(addv, i), (i << 16) | (j + 1));
+        ++hn;
+      }
+    }
+    // 3. outputs: lane = entry*8 + word
+    {
+      const uint32_t e = lane >> 3, w = lane & 7u;
+      const float es = __shfl(as, (int)e);
+      const uint32_t ey = __shfl(ay, (int)e), ex = __shfl(ax, (int)e);
+      if (e < L && w == 0)
+        *reinterpret_cast<uint2*>(cur + tg.own + e * sBlk + 2 * tg.c) = e < l ? make_uint2(f2u(es), ey) : make_uint2(kNegInfBits, 0u);
+      const uint32_t li = (ex >> 16) & 7u, lj = ex & 7u;
+      const uint32_t b1 = (uint32_t)__shfl((int)cb, (int)(li * 8 + lj));   // the entry's own back-pointer byte (per lane: no readlane here)
+      if (anchor) {
+        uint32_t wv2 = 0;
+        if (e < l) {
+          uint32_t mw[2 * P];
+          lazy_message<P>(x, li, lj, b1, mw);
+#pragma unroll
+          for (int u = 0; u < 2 * P; ++u) wv2 = w == (uint32_t)u ? mw[u] : wv2;
+        }
+        if (e < l && w < Wd) mout[tg.own + e * sBlk + 2 * g.N + msg_word_off(g.N, tg.c, w, tg.np_dst)] = wv2;
+      } else if (e < l && w == 0) {
+        reinterpret_cast<uint8_t*>(cur)[bp_byte_index(g, tg.own, e, tg.c)] = (uint8_t)((li << 3) | lj | (lazy_mbuf(x, li) << 6));
+      }
+    }
   }
 }
 
@@ -1387,12 +1767,12 @@ __global__ void lva_prepare_step(StepArgs a, SlotStep* __restrict__ steps) {
   const SlotDesc d = a.slots[z];
   const uint32_t t = a.launch_no - d.start;
   SlotStep ss;
-  ss.post_row = nullptr; ss.slot = z; ss.t = 0xFFFFFFFFu; ss.lo = 0; ss.hi = 0; ss.prev_hi = 0; ss.orient = 0;
+  ss.post_row = nullptr; ss.slot = z; ss.t = 0xFFFFFFFFu; ss.lo = 0; ss.hi = 0; ss.prev_hi = 0; ss.orient = 0; ss.flags = 0; ss.pad = 0;
   if (t < d.nblk) {
     const uint32_t b = d.band[t];
     ss.post_row = d.post + (size_t)t * 40;
-    ss.t = t; ss.lo = b & 0xFFFFu; ss.hi = b >> 16;
-    ss.prev_hi = t ? d.band[t - 1] >> 16 : 1u;       // what step t-1 wrote (only position 0 is initialised at t = 0)
+    ss.t = t; ss.lo = b & 0xFFFFu; ss.hi = (b >> 16) & 0x3FFFu; ss.flags = b >> 30;
+    ss.prev_hi = t ? (d.band[t - 1] >> 16) & 0x3FFFu : 1u;       // what step t-1 wrote (only position 0 is initialised at t = 0)
     ss.orient = d.orient;
   }
   steps[z] = ss;
@@ -1421,6 +1801,51 @@ __global__ void lva_gather_final(Geometry g, const DevCode* __restrict__ codes, 
   const DevCode& cd = codes[a.orient];
   const uint32_t pos = cd.npos - 1, c = cd.fin;
   const uint32_t* buf = trellis + (uint64_t)a.slot * g.sSlot + (uint64_t)a.parity * g.sPar;
+  if (g.lazy) {      // kernel mode 4: the last step's entries hold messages (even last step) or back-pointer bytes (odd)
+    const uint32_t* base = trellis + (uint64_t)a.slot * g.sSlot;
+    const uint32_t tl = a.nblk - 1, n = 8 * g.L * g.F;
+    uint32_t reach = 0;
+    const uint32_t T = cd.ptype[pos], pk = cd.predtab[T][c], sh = T == 0 ? 1u : 2u;
+    for (int b = 0; b < 4; ++b) if ((pk >> (4 * b)) & 8u) reach |= (0x11u << b);
+    if ((c & cd.vmask[pos]) != cd.vval[pos]) reach = 0;
+    const uint32_t nbp = sh == 1 ? (c >> (cd.m - 1)) : (2 * ((c >> (cd.m - 2)) & 1u) + (c >> (cd.m - 1)));
+    uint32_t* out = results + (uint64_t)a.read * n;
+    for (uint32_t e = threadIdx.x; e < 8 * g.L; e += blockDim.x) {
+      const uint32_t k = e / g.L, l = e % g.L;
+      uint32_t w[2 + 8];
+      w[0] = kNegInfBits;
+      for (uint32_t f = 1; f < g.F; ++f) w[f] = 0;
+      const uint32_t own = (uint32_t)(((uint64_t)(pos % g.R) * 8 + k) * g.sCrf);
+      if ((reach >> k) & 1u) {
+        w[0] = buf[own + l * g.sBlk + 2 * c]; w[1] = buf[own + l * g.sBlk + 2 * c + 1];
+        if (w[0] != kNegInfBits) {
+          if (!(tl & 1u)) {                      // messages stored by the last (anchor) step in buffer (tl >> 1) & 1
+            const uint32_t* mb = base + (uint64_t)((tl >> 1) & 1u) * g.sPar;
+            for (uint32_t f = 2; f < g.F; ++f) w[f] = msg_word(g, mb, own + l * g.sBlk, c, f - 2, cd.npair[pos]);
+          } else {                               // one hop back: the entry's source in step tl-1
+            const uint32_t bp = reinterpret_cast<const uint8_t*>(buf)[(own + l * g.sBlk + g.N * g.F) * 4u + c];
+            const uint32_t i = (bp >> 3) & 7u, j = bp & 7u;
+            const uint32_t* mb = base + (uint64_t)((bp >> 6) & 1u) * g.sPar;
+            uint32_t lst = own, conv = c, np = cd.npair[pos], s1 = 0;
+            if (i != 0) {
+              const uint32_t y = (pk >> (4 * (k & 3u))) & 7u;
+              conv = ((c << sh) | y) & (cd.nconv - 1);
+              lst = (uint32_t)(((uint64_t)((pos - 1) % g.R) * 8 + list_crf(k, i)) * g.sCrf);
+              np = cd.npair[pos - 1]; s1 = sh;
+            }
+            uint32_t carry = s1 ? nbp : 0u;
+            for (uint32_t f = 2; f < g.F; ++f) {
+              const uint32_t v = msg_word(g, mb, lst + j * g.sBlk, conv, f - 2, np);
+              w[f] = s1 ? ((v << s1) | carry) : v;
+              carry = s1 ? (v >> (32 - s1)) : 0u;
+            }
+          }
+        }
+      }
+      for (uint32_t f = 0; f < g.F; ++f) out[e * g.F + f] = w[f];
+    }
+    return;
+  }
   uint32_t reach = 0xFFu;
   if (pos > 0) {
     reach = 0;
@@ -1507,6 +1932,28 @@ int launch_step_fast(const StepArgs& a, const Geometry& g, const DevCode* codes,
     if (e) return e;
     if (ev_mid && (e = (int)hipEventRecord((hipEvent_t)ev_mid, st))) return e;
     hipLaunchKernelGGL(lva_step_fixup_wave, dim3(4096), dim3(256), 0, st, a, g, codes, trellis, hdr, items);
+    return (int)hipGetLastError();
+  }
+  if (g.lazy) {
+    dim3 grid(g.N / TS, a.band_max, a.nslots), block(8 * TS);
+#define LVA_LAZY_CASE(LLv, Pv) hipLaunchKernelGGL((lva_step_lazy<LLv, Pv>), grid, block, 0, st, a, g, codes, trellis, hdr, items)
+#define LVA_LAZY_L(LLv) switch (g.P) { case 1: LVA_LAZY_CASE(LLv, 1); break; case 2: LVA_LAZY_CASE(LLv, 2); break; \
+                                      case 3: LVA_LAZY_CASE(LLv, 3); break; case 4: LVA_LAZY_CASE(LLv, 4); break; default: return (int)hipErrorInvalidValue; }
+    switch (g.L) {
+      case 2: LVA_LAZY_L(2); break;
+      case 4: LVA_LAZY_L(4); break;
+      case 8: LVA_LAZY_L(8); break;
+      default: return (int)hipErrorInvalidValue;
+    }
+    e = (int)hipGetLastError();
+    if (e) return e;
+    if (ev_mid && (e = (int)hipEventRecord((hipEvent_t)ev_mid, st))) return e;
+    switch (g.P) {
+      case 1: hipLaunchKernelGGL((lva_step_fixup_lazy<1>), dim3(256), dim3(256), 0, st, a, g, codes, trellis, hdr, items); break;
+      case 2: hipLaunchKernelGGL((lva_step_fixup_lazy<2>), dim3(256), dim3(256), 0, st, a, g, codes, trellis, hdr, items); break;
+      case 3: hipLaunchKernelGGL((lva_step_fixup_lazy<3>), dim3(256), dim3(256), 0, st, a, g, codes, trellis, hdr, items); break;
+      default: hipLaunchKernelGGL((lva_step_fixup_lazy<4>), dim3(256), dim3(256), 0, st, a, g, codes, trellis, hdr, items); break;
+    }
     return (int)hipGetLastError();
   }
   switch (g.L) {
