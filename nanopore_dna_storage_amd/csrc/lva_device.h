@@ -82,7 +82,7 @@ struct StepArgs {
 
 struct Geometry {                // strides in 32-bit words
   uint32_t N, L, W, F, R, P;
-  uint32_t sBlk;                 // one (ring, crf, list entry) block = N*F (+ N/4 words of back-pointer bytes when lazy)
+  uint32_t sBlk;                 // one (ring, crf, list entry) block = N*F
   uint32_t lazy;                 // kernel mode 4: messages are materialised every second time step (lva_kernels.hip, "lazy")
   uint64_t sCrf, sRing, sPar, sSlot;
 };
@@ -92,8 +92,9 @@ inline Geometry make_geometry(uint32_t N, uint32_t L, uint32_t msg_bits, uint32_
   g.N = N; g.L = L; g.P = (msg_bits + 63) / 64; if (g.P == 0) g.P = 1;
   g.W = 2 * g.P; g.F = g.W + 2; g.R = R;
   g.lazy = lazy;
-  g.sBlk = N * g.F + (lazy ? N / 4 : 0);
-  g.sCrf = (uint64_t)g.sBlk * L; g.sRing = g.sCrf * 8;
+  g.sBlk = N * g.F;
+  // lazy mode: behind the L entry blocks of a (ring, crf) list, L back-pointer bytes per conv state ([conv][entry])
+  g.sCrf = (uint64_t)g.sBlk * L + (lazy ? (uint64_t)N * L / 4 : 0); g.sRing = g.sCrf * 8;
   g.sPar = g.sRing * R; g.sSlot = g.sPar * 2;
   return g;
 }

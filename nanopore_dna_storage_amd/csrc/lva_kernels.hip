@@ -674,6 +674,12 @@ __global__ __launch_bounds__(256) void lva_step_fixup_wave(StepArgs args, Geomet
 // ---------------------------------------------------------------------------------------
 namespace {
 
+#ifndef LVA_LAZY_ODD_MINWAVES
+#define LVA_LAZY_ODD_MINWAVES 8
+#endif
+#ifndef LVA_LAZY_GB
+#define LVA_LAZY_GB 2
+#endif
 #ifndef LVA_ACS_KERNEL
 #define LVA_ACS_KERNEL 1       // L == 1 runs lva_step_acs (256-thread workgroups) instead of lva_step_fast<1,P>
 #endif
@@ -683,8 +689,17 @@ constexpr uint32_t TS = 64;      // source conv states per workgroup tile (workg
 // `c ? a[i] : a[j]`, is folded by LLVM into a load from a selected ADDRESS, which pins the whole
 // array in scratch memory; routing the operands through an empty asm keeps them register values.
 template <typename T> __device__ __forceinline__ T opq(T x) { asm("" : "+v"(x)); return x; }
+// the same for a value that is uniform over the workgroup: stays in scalar registers
+__device__ __forceinline__ uint32_t opqs(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ const uint32_t* opqs(const uint32_t* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return (const uint32_t*)(((unsigned long long)hi << 32) | lo);
+}
 // c ? a : b on register values (both operands made opaque BEFORE the select: no control flow)
 template <typename T> __device__ __forceinline__ T selv(bool c, T a, T b) { a = opq(a); b = opq(b); return c ? a : b; }
+// c ? a : b where a and b are already plain values (scalars or registers): nothing to protect
+template <typename T> __device__ __forceinline__ T sel(bool c, T a, T b) { return c ? a : b; }
 
 // message of an entry (layout: msg_word_off above).  `ent` = the entry's block base + 2N (start of
 // its message region); words in planes >= np are zero and are not read
@@ -1120,7 +1135,7 @@ __global__ __launch_bounds__(8 * TS) void lva_step_fast(StepArgs args, Geometry 
 namespace {
 
 struct LazyCtx {
-  const uint32_t* M[2];          // the two parity buffers of the slot (message planes = message buffers 0 and 1)
+  const uint32_t* M0; const uint32_t* M1;   // the two parity buffers of the slot (message planes = message buffers 0 and 1)
   const uint8_t* bp_prev;        // back-pointer bytes of the previous step's buffer (anchor steps)
   uint32_t N, sBlk, sCrf, pw, m;
   uint32_t c, cp, k, own, src, src2;   // target conv, source conv, target crf; word offsets of (ring(pos),k), ring(pos-1), ring(pos-2)
@@ -1130,52 +1145,71 @@ struct LazyCtx {
   uint32_t t, fb, stale_pos1, stale_mb;  // time step; message buffer of fresh step t-1 entries; sources at pos-1 stale? its buffer
 };
 
+// byte index, inside a parity buffer, of the back-pointer byte of entry j of conv state `conv` of the list that starts at word
+// `list`: the bytes of a conv state's L entries are adjacent (one L-byte store per thread and odd step)
 __device__ __forceinline__ uint32_t bp_byte_index(const Geometry& g, uint32_t list, uint32_t j, uint32_t conv) {
-  return (list + j * g.sBlk + g.N * g.F) * 4u + conv;        // byte index into a parity buffer
+  return (list + g.L * g.sBlk) * 4u + conv * g.L + j;
 }
 
 // message buffer that holds the message of step t-1's entry of list i (odd steps)
-__device__ __forceinline__ uint32_t lazy_mbuf(const LazyCtx& x, uint32_t i) { return (i != 0 && x.stale_pos1) ? x.stale_mb : x.fb; }
+__device__ __forceinline__ uint32_t lazy_mbuf(const LazyCtx& x, uint32_t i) {
+  return sel(i != 0 && opqs(x.stale_pos1) != 0, opqs(x.stale_mb), opqs(x.fb));
+}
+
+// Where the stored message behind candidate (list i, index j) of the previous step lives, and the moves to apply to it:
+// *ent = message region, *conv / *np = conv index and planes in use there, (s1, n1) then (s2, nb_p) = shifts and new bits.
+// bp1 = the candidate's own back-pointer byte (anchor steps; ignored at odd steps).  false: the message is empty (t = 0).
+// (Selections between fields of the context go through selv: a select between two loads would pin the struct in scratch.)
+__device__ __forceinline__ bool lazy_locate(const LazyCtx& x, uint32_t i, uint32_t j, uint32_t bp1, const uint32_t** ent, uint32_t* conv,
+                                            uint32_t* np, uint32_t* s1, uint32_t* n1, uint32_t* s2) {
+  const uint32_t kk = i == 0 ? x.k : list_crf(x.k, i);
+  const uint32_t own = opq(x.own), c = opq(x.c), cp = opq(x.cp);
+  const uint32_t src = opqs(x.src), src2 = opqs(x.src2);                         // (uniform over the workgroup)
+  const uint32_t np_p = opqs(x.np_p), np_p1 = opqs(x.np_p1), np_p2 = opqs(x.np_p2), sh_p = opqs(x.sh_p);
+  const uint32_t* M0 = opqs(x.M0); const uint32_t* M1 = opqs(x.M1);
+  *s1 = 0; *n1 = 0;
+  const bool stay = i == 0;
+  if (x.t & 1u) {                                            // odd step: step t-1's entries carry their messages
+    const uint32_t lst = sel(stay, own, src + mul24(kk, x.sCrf));
+    *ent = sel(lazy_mbuf(x, i) != 0, M1, M0) + lst + mul24(j, x.sBlk) + x.pw;
+    *conv = sel(stay, c, cp); *np = sel(stay, np_p, np_p1); *s2 = sel(stay, 0u, sh_p);
+    return true;
+  }
+  *s2 = sel(stay, 0u, sh_p);
+  if (x.t == 0) { *ent = M0; *conv = 0; *np = 1; return false; }   // the initial entries: empty message
+  const uint32_t i1 = (bp1 >> 3) & 7u, j1 = bp1 & 7u;
+  const bool stay1 = i1 == 0;
+  // four cases: (stay, stay) own state; (stay, move) and (move, stay) the source state at pos-1; (move, move) pos-2
+  const uint32_t y1 = (x.pk1 >> (4 * (kk & 3u))) & 7u;
+  const uint32_t cpp = ((cp << x.sh_q) | y1) & (x.N - 1u);
+  const uint32_t crf1 = list_crf(kk, stay1 ? 1u : i1);       // crf of the second hop's source when it is a move
+  const uint32_t l_ss = own, l_sm = src + mul24(crf1, x.sCrf), l_ms = src + mul24(kk, x.sCrf), l_mm = src2 + mul24(crf1, x.sCrf);
+  const uint32_t lst = sel(stay, sel(stay1, l_ss, l_sm), sel(stay1, l_ms, l_mm));
+  *conv = sel(stay, sel(stay1, c, cp), sel(stay1, cp, cpp));
+  *np = sel(stay, sel(stay1, np_p, np_p1), sel(stay1, np_p1, np_p2));
+  const bool mm = !stay && !stay1;
+  *s1 = sel(mm, opqs(x.sh_q), 0u); *n1 = sel(mm, opq(x.nb_q), 0u);
+  *s2 = sel(stay && stay1, 0u, sh_p);
+  *ent = sel(((bp1 >> 6) & 1u) != 0, M1, M0) + lst + mul24(j1, x.sBlk) + x.pw;
+  return true;
+}
 
 // Message of candidate (list i, index j) of the previous step AS IT WOULD STAND IN THE TARGET (all moves applied).
-// bp1 = the candidate's own back-pointer byte (anchor steps; ignored at odd steps).
 template <int P>
 __device__ __forceinline__ void lazy_message(const LazyCtx& x, uint32_t i, uint32_t j, uint32_t bp1, uint32_t (&mw)[2 * P]) {
-  const uint32_t kk = i == 0 ? x.k : list_crf(x.k, i);
-  if (x.t & 1u) {                                            // odd step: step t-1's entries carry their messages
-    const uint32_t lst = i == 0 ? x.own : x.src + mul24(kk, x.sCrf);
-    load_msg<P>(x.M[lazy_mbuf(x, i)] + lst + mul24(j, x.sBlk) + x.pw, x.N, i == 0 ? x.c : x.cp, i == 0 ? x.np_p : x.np_p1, mw);
-    push_bits<2 * P>(mw, i == 0 ? 0u : x.sh_p, x.nb_p);
-    return;
-  }
-  if (x.t == 0) {                                            // the initial entries: empty message
+  const uint32_t* ent; uint32_t conv, np, s1, n1, s2;
+  if (lazy_locate(x, i, j, bp1, &ent, &conv, &np, &s1, &n1, &s2)) load_msg<P>(ent, x.N, conv, np, mw);
+  else {
 #pragma unroll
     for (int w = 0; w < 2 * P; ++w) mw[w] = 0;
-    push_bits<2 * P>(mw, i == 0 ? 0u : x.sh_p, x.nb_p);
-    return;
   }
-  const uint32_t i1 = (bp1 >> 3) & 7u, j1 = bp1 & 7u, mb = (bp1 >> 6) & 1u;
-  uint32_t lst, conv, np, s1 = 0, n1 = 0;
-  if (i == 0) {                                              // candidate = own state one step ago
-    if (i1 == 0) { lst = x.own; conv = x.c; np = x.np_p; }
-    else { lst = x.src + mul24(list_crf(x.k, i1), x.sCrf); conv = x.cp; np = x.np_p1; }
-  } else {                                                   // candidate = state (pos-1, cp, kk) one step ago
-    if (i1 == 0) { lst = x.src + mul24(kk, x.sCrf); conv = x.cp; np = x.np_p1; }
-    else {
-      const uint32_t y1 = (x.pk1 >> (4 * (kk & 3u))) & 7u;
-      conv = ((x.cp << x.sh_q) | y1) & (x.N - 1u);
-      lst = x.src2 + mul24(list_crf(kk, i1), x.sCrf); np = x.np_p2;
-      s1 = x.sh_q; n1 = x.nb_q;
-    }
-  }
-  load_msg<P>(x.M[mb] + lst + mul24(j1, x.sBlk) + x.pw, x.N, conv, np, mw);
   push_bits<2 * P>(mw, s1, n1);
-  push_bits<2 * P>(mw, (i != 0 || i1 != 0) ? x.sh_p : 0u, x.nb_p);
+  push_bits<2 * P>(mw, s2, x.nb_p);
 }
 
 __device__ __forceinline__ void lazy_ctx(const DevCode& cd, const Geometry& g, const SlotStep& ss, const uint32_t* slot_base, uint32_t pos,
                                          uint32_t c, uint32_t cp, uint32_t k, uint32_t own, LazyCtx* x) {
-  x->M[0] = slot_base; x->M[1] = slot_base + g.sPar;
+  x->M0 = slot_base; x->M1 = slot_base + g.sPar;
   x->bp_prev = reinterpret_cast<const uint8_t*>(slot_base + (uint64_t)(ss.t & 1u) * g.sPar);
   x->N = g.N; x->sBlk = g.sBlk; x->sCrf = (uint32_t)g.sCrf; x->pw = 2 * g.N; x->m = cd.m;
   x->c = c; x->cp = cp; x->k = k; x->own = own;
@@ -1187,7 +1221,7 @@ __device__ __forceinline__ void lazy_ctx(const DevCode& cd, const Geometry& g, c
   const uint32_t Tq = pos >= 1 ? cd.ptype[pos - 1] : 0u;
   x->sh_q = Tq == 0 ? 1u : 2u;
   x->nb_q = x->sh_q == 1 ? (cp >> (cd.m - 1)) : (2 * ((cp >> (cd.m - 2)) & 1u) + (cp >> (cd.m - 1)));
-  x->pk1 = pos >= 2 ? cd.predtab[Tq][cp] : 0u;
+  x->pk1 = (pos >= 2 && !(ss.t & 1u)) ? cd.predtab[Tq][cp] : 0u;
   x->np_p = cd.npair[pos]; x->np_p1 = pos >= 1 ? cd.npair[pos - 1] : 1u; x->np_p2 = pos >= 2 ? cd.npair[pos - 2] : 1u;
   x->t = ss.t; x->fb = ((ss.t - 1u) >> 1) & 1u;
   x->stale_pos1 = (pos == ss.lo) && (ss.flags & 1u);
@@ -1196,41 +1230,78 @@ __device__ __forceinline__ void lazy_ctx(const DevCode& cd, const Geometry& g, c
 
 // Output phase of one target on the lazy path.  false = a fingerprint match did not survive the comparison of the
 // full messages (collision): the exact path redoes the target.
-template <int LL, int P>
+// own_bp: the back-pointer bytes of the target's own (stay) list in the previous buffer, entry j in byte j (anchor steps).
+template <int LL, int P, bool ANCHOR>
 __device__ __forceinline__ bool lazy_output(const Geometry& g, const LazyCtx& x, uint32_t* __restrict__ cur, uint32_t* __restrict__ mout,
-                                            const uint8_t* s_bp, uint32_t sc, unsigned long long asrc, unsigned long long rej0,
-                                            unsigned long long rej1, uint32_t lc) {
+                                            const uint8_t* s_bp, uint32_t sc, unsigned long long own_bp, unsigned long long asrc,
+                                            unsigned long long rej0, unsigned long long rej1, uint32_t lc) {
   bool good = true;
-  const bool anchor = !(x.t & 1u);
-  // the candidate's own back-pointer byte (anchor steps): staged in LDS for source lists, in the previous buffer for the stay list
-  auto bp_of = [&](uint32_t i, uint32_t j) -> uint32_t {
-    if (!anchor || x.t == 0) return 0u;
-    if (i == 0) return x.bp_prev[bp_byte_index(g, x.own, j, x.c)];
-    return s_bp[(mul24(list_crf(x.k, i), LL) + j) * TS + sc];
+  // the candidate's own back-pointer byte: staged in LDS for source lists, prefetched for the stay list
+  auto bp_of = [&](uint32_t i, uint32_t j) __attribute__((always_inline)) -> uint32_t {
+    if (i == 0) return (uint32_t)(own_bp >> (8 * j)) & 0xFFu;
+    return s_bp[(list_crf(x.k, i) * TS + sc) * LL + j];
   };
-  uint8_t* bp_cur = reinterpret_cast<uint8_t*>(cur);
+  // every fingerprint match filed under entry l must be the same message as the entry's (mw)
+  auto verify = [&](int l, const uint32_t (&mw)[2 * P]) __attribute__((always_inline)) {
 #pragma unroll
-  for (int l = 0; l < LL; ++l) {
-    if ((uint32_t)l < lc) {
-      const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu;
-      const uint32_t i = a8 >> 3, j = a8 & 7u;
-      const uint32_t r0 = (uint32_t)(rej0 >> (7 * l)) & 0x7Fu;
-      uint32_t mw[2 * P];
-      if (anchor || r0) lazy_message<P>(x, i, j, bp_of(i, j), mw);
-      if (anchor) store_msg<P>(mout + x.own + l * x.sBlk + x.pw, x.N, x.c, x.np_p, mw);
-      else bp_cur[bp_byte_index(g, x.own, l, x.c)] = (uint8_t)(a8 | (lazy_mbuf(x, i) << 6));
-      if (r0) {
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const uint32_t rec = (uint32_t)((s2 ? rej1 : rej0) >> (7 * l)) & 0x7Fu;
+      if (rec & 0x40u) {
+        const uint32_t ri = (rec >> 3) & 7u, rj = rec & 7u;
+        uint32_t qm[2 * P];
+        lazy_message<P>(x, ri, rj, bp_of(ri, rj), qm);
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const uint32_t rec = s2 ? (uint32_t)(rej1 >> (7 * l)) & 0x7Fu : r0;
-          if (rec & 0x40u) {
-            const uint32_t ri = (rec >> 3) & 7u, rj = rec & 7u;
-            uint32_t qm[2 * P];
-            lazy_message<P>(x, ri, rj, bp_of(ri, rj), qm);
+        for (int w = 0; w < 2 * P; ++w) good &= (qm[w] == mw[w]);
+      }
+    }
+  };
+  if constexpr (!ANCHOR) {
+    // ---- odd step: one byte per accepted entry; messages are touched only to confirm fingerprint matches ----
+    unsigned long long packed = 0;
 #pragma unroll
-            for (int w = 0; w < 2 * P; ++w) good &= (qm[w] == mw[w]);
-          }
+    for (int l = 0; l < LL; ++l) {
+      if ((uint32_t)l < lc) {
+        const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu;
+        packed |= (unsigned long long)(a8 | (lazy_mbuf(x, a8 >> 3) << 6)) << (8 * l);
+        if ((uint32_t)(rej0 >> (7 * l)) & 0x40u) {
+          uint32_t mw[2 * P];
+          lazy_message<P>(x, a8 >> 3, a8 & 7u, 0u, mw);
+          verify(l, mw);
         }
+      }
+    }
+    uint8_t* dst = reinterpret_cast<uint8_t*>(cur) + bp_byte_index(g, x.own, 0, x.c);
+    if constexpr (LL == 8) *reinterpret_cast<unsigned long long*>(dst) = packed;
+    else if constexpr (LL == 4) *reinterpret_cast<uint32_t*>(dst) = (uint32_t)packed;
+    else *reinterpret_cast<uint16_t*>(dst) = (uint16_t)packed;
+    return good;
+  }
+  // ---- anchor step: two hops to the stored message, both moves applied, stored coalesced; LVA_LAZY_GB entries in flight ----
+  constexpr int GB = LL >= LVA_LAZY_GB ? LVA_LAZY_GB : LL;
+#pragma unroll
+  for (int l0 = 0; l0 < LL; l0 += GB) {
+    uint32_t m[GB][2 * P], s1[GB], n1[GB], s2[GB];
+#pragma unroll
+    for (int u = 0; u < GB; ++u) {
+      const int l = l0 + u;
+      s1[u] = 0; n1[u] = 0; s2[u] = 0;
+#pragma unroll
+      for (int w = 0; w < 2 * P; ++w) m[u][w] = 0;
+      if ((uint32_t)l < lc) {
+        const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu;
+        const uint32_t i = a8 >> 3, j = a8 & 7u;
+        const uint32_t* ent; uint32_t conv, np;
+        if (lazy_locate(x, i, j, bp_of(i, j), &ent, &conv, &np, &s1[u], &n1[u], &s2[u])) load_msg<P>(ent, x.N, conv, np, m[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < GB; ++u) {
+      const int l = l0 + u;
+      if ((uint32_t)l < lc) {
+        push_bits<2 * P>(m[u], s1[u], n1[u]);
+        push_bits<2 * P>(m[u], s2[u], x.nb_p);
+        store_msg<P>(mout + x.own + l * x.sBlk + x.pw, x.N, x.c, x.np_p, m[u]);
+        if ((uint32_t)(rej0 >> (7 * l)) & 0x40u) verify(l, m[u]);
       }
     }
   }
@@ -1239,13 +1310,15 @@ __device__ __forceinline__ bool lazy_output(const Geometry& g, const LazyCtx& x,
 
 }  // namespace
 
-// grid / block as lva_step_fast.
-template <int LL, int P>
-__global__ __launch_bounds__(8 * TS) void lva_step_lazy(StepArgs args, Geometry g, const DevCode* __restrict__ codes,
+// grid / block as lva_step_fast.  Two instances per step: ANCHOR = true serves the slots whose time step is even,
+// ANCHOR = false those at an odd step (workgroups of the other kind leave at once) -- the odd-step path keeps the
+// merge's small register footprint (no message in flight), the anchor path is the only one that pays for two hops.
+template <int LL, int P, bool ANCHOR>
+__global__ __launch_bounds__(8 * TS, ANCHOR ? 1 : LVA_LAZY_ODD_MINWAVES) void lva_step_lazy(StepArgs args, Geometry g, const DevCode* __restrict__ codes,
                                                      uint32_t* __restrict__ trellis, WorkHdr* __restrict__ hdr,
                                                      uint32_t* __restrict__ items) {
   __shared__ uint2 s_src[8 * LL * TS];
-  __shared__ uint8_t s_bp[8 * LL * TS];
+  __shared__ uint8_t s_bp[ANCHOR ? 8 * LL * TS : 4];
   __shared__ float s_post[40];
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
     hdr->count[args.step_parity ^ 1u] = 0;     // the other parity's list was consumed by the last fix-up
@@ -1253,6 +1326,7 @@ __global__ __launch_bounds__(8 * TS) void lva_step_lazy(StepArgs args, Geometry 
   }
   SlotStep ss;
   if (!load_slot(args, blockIdx.z, &ss)) return;
+  if (!(ss.t & 1u) != ANCHOR) return;
   const uint32_t pos = ss.lo + blockIdx.y;
   if (pos >= ss.hi) return;
   const DevCode& cd = codes[ss.orient];
@@ -1260,7 +1334,7 @@ __global__ __launch_bounds__(8 * TS) void lva_step_lazy(StepArgs args, Geometry 
   uint32_t* slot_base = trellis + (uint64_t)ss.slot * g.sSlot;
   const uint32_t* prev; uint32_t* cur;
   slot_buffers(ss, g, trellis, &prev, &cur);
-  const bool anchor = !(ss.t & 1u);
+  constexpr bool anchor = ANCHOR;
   uint32_t* mout = slot_base + (uint64_t)((ss.t >> 1) & 1u) * g.sPar;      // message buffer an anchor step writes
 
   if (pos == 0) {                          // stay-only update of the 8 start states (:706-713); their message stays empty
@@ -1281,14 +1355,16 @@ __global__ __launch_bounds__(8 * TS) void lva_step_lazy(StepArgs args, Geometry 
   const uint32_t src = (uint32_t)((uint64_t)((pos - 1) % g.R) * 8 * g.sCrf);
   for (uint32_t chunk = tid; chunk < 8u * LL * (TS / 2); chunk += 8u * TS) {
     const uint32_t rowi = chunk / (TS / 2), lane2 = chunk % (TS / 2);       // rowi = crf * LL + l
-    const uint4 v = *reinterpret_cast<const uint4*>(prev + src + (uint64_t)rowi * g.sBlk + 2 * (tile * TS) + 4 * lane2);
+    const uint4 v = *reinterpret_cast<const uint4*>(prev + src + (uint64_t)(rowi / LL) * g.sCrf + (uint64_t)(rowi % LL) * g.sBlk +
+                                                    2 * (tile * TS) + 4 * lane2);
     *reinterpret_cast<uint4*>(&s_src[rowi * TS + 2 * lane2]) = v;
   }
-  if (anchor && ss.t != 0) {
-    for (uint32_t chunk = tid; chunk < 8u * LL * (TS / 4); chunk += 8u * TS) {
-      const uint32_t rowi = chunk / (TS / 4), q4 = chunk % (TS / 4);
-      const uint32_t v = prev[src + (uint64_t)rowi * g.sBlk + N * g.F + (tile * TS) / 4 + q4];
-      *reinterpret_cast<uint32_t*>(&s_bp[rowi * TS + 4 * q4]) = v;
+  if (anchor && ss.t != 0) {              // per crf: the L bytes of 64 conv states = TS*LL contiguous bytes
+    constexpr uint32_t kW = TS * LL / 4;   // words per crf
+    for (uint32_t chunk = tid; chunk < 8u * kW; chunk += 8u * TS) {
+      const uint32_t kk = chunk / kW, w = chunk % kW;
+      const uint32_t v = prev[src + (uint64_t)kk * g.sCrf + (uint64_t)LL * g.sBlk + (tile * TS * LL) / 4 + w];
+      *reinterpret_cast<uint32_t*>(&s_bp[kk * TS * LL + 4 * w]) = v;
     }
   }
   if (tid < 40) s_post[tid] = ss.post_row[tid];
@@ -1296,6 +1372,14 @@ __global__ __launch_bounds__(8 * TS) void lva_step_lazy(StepArgs args, Geometry 
 
   TileTarget t;
   if (!tile_target<TS>(cd, g, ss, pos, tile, tid, &t)) return;
+  // an anchor step needs the back-pointer bytes of its own (stay) list: requested now, used after the merge
+  unsigned long long own_bp = 0;
+  if (anchor && ss.t != 0 && (t.ok & 1u)) {
+    const uint8_t* bpp = reinterpret_cast<const uint8_t*>(prev) + bp_byte_index(g, t.own, 0, t.c);
+    if constexpr (LL == 8) own_bp = *reinterpret_cast<const unsigned long long*>(bpp);
+    else if constexpr (LL == 4) own_bp = *reinterpret_cast<const uint32_t*>(bpp);
+    else own_bp = *reinterpret_cast<const uint16_t*>(bpp);
+  }
   unsigned long long asrc = 0, rej0 = 0, rej1 = 0;
   uint32_t lc = 0;
   int why = t.k < 4 ? fast_merge_core<LL, 8>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &rej1, &lc)
@@ -1303,7 +1387,7 @@ __global__ __launch_bounds__(8 * TS) void lva_step_lazy(StepArgs args, Geometry 
   if (!why) {
     LazyCtx x;
     lazy_ctx(cd, g, ss, slot_base, pos, t.c, t.cp, t.k, t.own, &x);
-    if (!lazy_output<LL, P>(g, x, cur, mout, s_bp, t.sc, asrc, rej0, rej1, lc)) why = 4;
+    if (!lazy_output<LL, P, ANCHOR>(g, x, cur, mout, s_bp, t.sc, own_bp, asrc, rej0, rej1, lc)) why = 4;
   }
   if (why) {
     atomicAdd(&hdr->reason[why - 1], 1ull);
@@ -1788,7 +1872,7 @@ __global__ void lva_init_slot(Geometry g, const DevCode* __restrict__ codes, uin
   const uint32_t n = 8 * g.L * g.F;
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
     const uint32_t f = i % g.F, l = (i / g.F) % g.L, k = i / (g.F * g.L);
-    const uint64_t blk = ((uint64_t)k * g.L + l) * g.sBlk;     // ring slot 0 = position 0
+    const uint64_t blk = (uint64_t)k * g.sCrf + (uint64_t)l * g.sBlk;     // ring slot 0 = position 0
     par0[blk + plane_off(g, f >> 1, cd.init) + (f & 1u)] = (f == 0 && l > 0) ? kNegInfBits : 0u;
   }
 }
@@ -1823,7 +1907,7 @@ __global__ void lva_gather_final(Geometry g, const DevCode* __restrict__ codes, 
             const uint32_t* mb = base + (uint64_t)((tl >> 1) & 1u) * g.sPar;
             for (uint32_t f = 2; f < g.F; ++f) w[f] = msg_word(g, mb, own + l * g.sBlk, c, f - 2, cd.npair[pos]);
           } else {                               // one hop back: the entry's source in step tl-1
-            const uint32_t bp = reinterpret_cast<const uint8_t*>(buf)[(own + l * g.sBlk + g.N * g.F) * 4u + c];
+            const uint32_t bp = reinterpret_cast<const uint8_t*>(buf)[bp_byte_index(g, own, l, c)];
             const uint32_t i = (bp >> 3) & 7u, j = bp & 7u;
             const uint32_t* mb = base + (uint64_t)((bp >> 6) & 1u) * g.sPar;
             uint32_t lst = own, conv = c, np = cd.npair[pos], s1 = 0;
@@ -1936,7 +2020,8 @@ int launch_step_fast(const StepArgs& a, const Geometry& g, const DevCode* codes,
   }
   if (g.lazy) {
     dim3 grid(g.N / TS, a.band_max, a.nslots), block(8 * TS);
-#define LVA_LAZY_CASE(LLv, Pv) hipLaunchKernelGGL((lva_step_lazy<LLv, Pv>), grid, block, 0, st, a, g, codes, trellis, hdr, items)
+#define LVA_LAZY_CASE(LLv, Pv) { hipLaunchKernelGGL((lva_step_lazy<LLv, Pv, true>), grid, block, 0, st, a, g, codes, trellis, hdr, items); \
+                                 hipLaunchKernelGGL((lva_step_lazy<LLv, Pv, false>), grid, block, 0, st, a, g, codes, trellis, hdr, items); }
 #define LVA_LAZY_L(LLv) switch (g.P) { case 1: LVA_LAZY_CASE(LLv, 1); break; case 2: LVA_LAZY_CASE(LLv, 2); break; \
                                       case 3: LVA_LAZY_CASE(LLv, 3); break; case 4: LVA_LAZY_CASE(LLv, 4); break; default: return (int)hipErrorInvalidValue; }
     switch (g.L) {
