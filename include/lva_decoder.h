@@ -50,10 +50,12 @@ typedef struct lva_config {
   uint32_t sync_period;
   int32_t device;           /* HIP device ordinal */
   int32_t max_slots;        /* reads in flight on the device; 0 = choose from free HBM */
-  int32_t kernel;           /* 0 = default (2 where available, else 3, else 1); 1 = exact kernel, one thread per
-                               target; 2 = fast kernel + exact fix-up (L = 1, 2, 4, 8: lva_step_fast; any other
-                               2 <= L <= 64: lva_step_big); 3 = exact kernel, one wavefront per target
-                               (2 <= L <= 64) */
+  int32_t kernel;           /* 0 = default (4 where it is the faster one, else 2 where available, else 3, else 1);
+                               1 = exact kernel, one thread per target; 2 = fast kernel + exact fix-up (L = 1, 2, 4, 8:
+                               lva_step_fast / lva_step_acs; any other 2 <= L <= 64: lva_step_big); 3 = exact kernel, one
+                               wavefront per target (2 <= L <= 64); 4 = fast kernel with lazy messages (L = 2, 4, 8:
+                               messages materialised every second time step, lva_step_lazy).  Every mode gives the
+                               reference's lists bit for bit */
   uint64_t mem_budget_bytes;/* cap on trellis memory; 0 = 60% of free HBM */
 } lva_config;
 

@@ -212,8 +212,11 @@ int lva_decoder_create(const lva_config* cfg, lva_decoder** out) {
   d->max_dev = cfg->max_deviation == LVA_MAX_DEVIATION_DEFAULT ? c.msg_len + (uint32_t)c.mem_conv + 1 : cfg->max_deviation;
   // kernel mode 4 ("lazy", list sizes 2, 4, 8): messages are materialised every second time step and carried as one-byte
   // back-pointers in between; two-hop chains reach one position further below the band, hence one more ring position
-  const bool lazy = cfg->kernel == 4;
-  if (lazy && !(cfg->list_size == 2 || cfg->list_size == 4 || cfg->list_size == 8)) { delete d; return LVA_ERR_UNSUPPORTED; }
+  // Default (kernel 0) where it is the faster one: list sizes 2 / 4 / 8 with at most three message planes (m = 11 L = 8: +5 %,
+  // m = 8: +9 %; with four planes -- m = 14, msg_len 180 -- the anchor step's registers cost more than the bytes save: -10 %).
+  const bool lazy_ok = (cfg->list_size == 2 || cfg->list_size == 4 || cfg->list_size == 8) && c.nconv >= 64;
+  if (cfg->kernel == 4 && !lazy_ok) { delete d; return LVA_ERR_UNSUPPORTED; }
+  const bool lazy = cfg->kernel == 4 || (cfg->kernel == 0 && lazy_ok && c.msg_bits() <= 192);
   const uint64_t ring = std::min<uint64_t>(c.npos, 2ull * d->max_dev + (lazy ? 2 : 1));
   d->g = make_geometry(c.nconv, cfg->list_size, c.msg_bits(), (uint32_t)std::max<uint64_t>(ring, 1), lazy ? 1u : 0u);
   if (d->g.sPar >= ((uint64_t)1 << 32)) { delete d; return LVA_ERR_TOO_MANY_STATES; }
@@ -256,7 +259,7 @@ int lva_decoder_create(const lva_config* cfg, lva_decoder** out) {
   if (cfg->kernel == 2 && !fast_ok) return fail(LVA_ERR_UNSUPPORTED);
   // 1 = exact (one thread per target), 2 = fast + fix-up, 3 = wavefront per target (lists of 9..64 entries)
   if (cfg->kernel == 3 && !wave_kernel_available(d->g)) return fail(LVA_ERR_UNSUPPORTED);
-  d->kernel = cfg->kernel == 1 ? 1 : cfg->kernel == 3 ? 3 : cfg->kernel == 4 ? 4 : (fast_ok ? 2 : (wave_kernel_available(d->g) ? 3 : 1));
+  d->kernel = cfg->kernel == 1 ? 1 : cfg->kernel == 3 ? 3 : lazy ? 4 : (fast_ok ? 2 : (wave_kernel_available(d->g) ? 3 : 1));
   if (d->kernel == 4 && (!fast_ok || c.nconv < 64)) return fail(LVA_ERR_UNSUPPORTED);
   d->prof.kernel = d->kernel;
   if (const char* cap = std::getenv("LVA_WORK_CAP")) {       // tests: force the work-list overflow path

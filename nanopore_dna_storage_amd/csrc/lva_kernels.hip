@@ -1280,26 +1280,27 @@ __device__ __forceinline__ bool lazy_output(const Geometry& g, const LazyCtx& x,
   constexpr int GB = LL >= LVA_LAZY_GB ? LVA_LAZY_GB : LL;
 #pragma unroll
   for (int l0 = 0; l0 < LL; l0 += GB) {
-    uint32_t m[GB][2 * P], s1[GB], n1[GB], s2[GB];
+    uint32_t m[GB][2 * P], mv[GB];                         // mv: the moves to apply, packed (s1 | n1 << 2 | s2 << 4)
 #pragma unroll
     for (int u = 0; u < GB; ++u) {
       const int l = l0 + u;
-      s1[u] = 0; n1[u] = 0; s2[u] = 0;
+      mv[u] = 0;
 #pragma unroll
       for (int w = 0; w < 2 * P; ++w) m[u][w] = 0;
       if ((uint32_t)l < lc) {
         const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu;
         const uint32_t i = a8 >> 3, j = a8 & 7u;
-        const uint32_t* ent; uint32_t conv, np;
-        if (lazy_locate(x, i, j, bp_of(i, j), &ent, &conv, &np, &s1[u], &n1[u], &s2[u])) load_msg<P>(ent, x.N, conv, np, m[u]);
+        const uint32_t* ent; uint32_t conv, np, s1, n1, s2;
+        if (lazy_locate(x, i, j, bp_of(i, j), &ent, &conv, &np, &s1, &n1, &s2)) load_msg<P>(ent, x.N, conv, np, m[u]);
+        mv[u] = s1 | (n1 << 2) | (s2 << 4);
       }
     }
 #pragma unroll
     for (int u = 0; u < GB; ++u) {
       const int l = l0 + u;
       if ((uint32_t)l < lc) {
-        push_bits<2 * P>(m[u], s1[u], n1[u]);
-        push_bits<2 * P>(m[u], s2[u], x.nb_p);
+        push_bits<2 * P>(m[u], mv[u] & 3u, (mv[u] >> 2) & 3u);
+        push_bits<2 * P>(m[u], mv[u] >> 4, x.nb_p);
         store_msg<P>(mout + x.own + l * x.sBlk + x.pw, x.N, x.c, x.np_p, m[u]);
         if ((uint32_t)(rej0 >> (7 * l)) & 0x40u) verify(l, m[u]);
       }

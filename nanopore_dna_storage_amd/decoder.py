@@ -101,10 +101,10 @@ def algorithmic_bytes(mem_conv, rate, msg_len, nblk, list_size, max_deviation=No
 class Decoder:
     """A list-Viterbi decoder bound to one GPU.  Fails loudly without a GPU (no CPU path).
 
-    kernel: 0 = default (fast kernels + exact fix-up for list sizes up to 64; the thread-per-target exact
-    kernel beyond), 1 = thread-per-target exact kernel, 2 = fast kernel + fix-up, 3 = wavefront-per-target
-    exact kernel.  All modes give the
-    reference's lists bit for bit; they differ in speed only."""
+    kernel: 0 = default (the fastest mode for the configuration: 4 for list sizes 2 / 4 / 8 with up to 192 message bits,
+    else 2 for list sizes up to 64, the thread-per-target exact kernel beyond), 1 = thread-per-target exact kernel,
+    2 = fast kernel + exact fix-up, 3 = wavefront-per-target exact kernel, 4 = fast kernel with lazy messages
+    (materialised every second time step).  All modes give the reference's lists bit for bit; they differ in speed only."""
 
     def __init__(self, mem_conv, rate, msg_len, list_size=1, max_deviation=None, sync_marker="", sync_period=0,
                  device=0, max_slots=0, kernel=0, mem_budget_bytes=0):
