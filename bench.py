@@ -254,7 +254,8 @@ def main():
                 pth = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(pth):
                     tj = json.load(open(pth))
-                    if (a.mem_conv, a.rate, a.list_size, a.msg_len, a.max_deviation) == (11, 5, 8, 180, 20) and acc["launches"]:
+                    if ((a.mem_conv, a.rate, a.list_size, a.msg_len, a.max_deviation) == (11, 5, 8, 180, 20) and acc["launches"]
+                            and tj.get("kernel_mode", 2) == prof["kernel"]):
                         per_rs = (tj["fetch_correction"] * tj["fetch_size_kb_per_launch"] + tj["write_size_kb_per_launch"]) * 1024.0 / tj["slots"]
                         traffic = per_rs * (acc["read_steps"] / acc["launches"])
                         tsrc = "profiles/" + name + " (PMC run of an earlier invocation, scaled per read-step)"
