@@ -886,12 +886,12 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
     for (int i = 0; i < NL; ++i) eq[i] = h[i] == M;
     // first and last head equal to the maximum; they differ when equal scores sit on top, and
     // then libstdc++'s heap order decides
-    uint32_t sel = NL - 1, last = 0;
+    uint32_t sel = NL - 1;
 #pragma unroll
     for (int i = NL - 2; i >= 0; --i) sel = eq[i] ? (uint32_t)i : sel;
+    bool two = false, seen = eq[0];        // two heads at the maximum: lane-mask logic, no vector instruction
 #pragma unroll
-    for (int i = 1; i < NL; ++i) last = eq[i] ? (uint32_t)i : last;
-    const bool two = sel != last;
+    for (int i = 1; i < NL; ++i) { two = two || (eq[i] && seen); seen = seen || eq[i]; }
     const bool alive = M > NEG;            // false: every list exhausted (heap empty)
     const bool proceed = alive && !two;
     const uint32_t j = (ptr >> (4 * sel)) & 15u;
@@ -907,13 +907,14 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
     const bool bad = !is_stay && nxt_ok && !(ns_src > NEG);   // overflowed to -inf: the reference would still queue it
     const uint32_t ch = selv(is_stay, st_h[0], fp_src);
     const float ns = selv(is_stay, LL > 1 ? st_s[LL > 1 ? 1 : 0] : NEG, ns_src);
-    // the stay list is consumed front to back: slide it when it was popped
+    // the stay list is consumed front to back: slide it when it was popped.  A real branch on purpose (predicated
+    // v_mov): a run of VOP2 v_cndmask on one condition issues at ~23 cycles each on gfx950 (scripts/ubench/valu_rates.hip)
+    if (is_stay) {
+      asm volatile("" ::: "memory");
 #pragma unroll
-    for (int l = 0; l + 1 < LL; ++l) {
-      st_s[l] = selv(is_stay, st_s[l + 1], st_s[l]);
-      st_h[l] = selv(is_stay, st_h[l + 1], st_h[l]);
+      for (int l = 0; l + 1 < LL; ++l) { st_s[l] = opq(st_s[l + 1]); st_h[l] = opq(st_h[l + 1]); }
+      st_s[LL - 1] = NEG;
     }
-    st_s[LL - 1] = selv(is_stay, NEG, st_s[LL - 1]);
     // de-duplicate on fingerprints (:778-779): position q in ah <-> accepted entry lc-1-q
     int q = -1;
 #pragma unroll
@@ -925,12 +926,14 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
     const bool full0 = reject && ((rej0 >> (s7 & 63u)) & 0x40u), full1 = reject && ((rej1 >> (s7 & 63u)) & 0x40u);
     rej0 |= (reject && !full0) ? rec << (s7 & 63u) : 0ull;
     rej1 |= (full0 && !full1) ? rec << (s7 & 63u) : 0ull;
-    if (accept) *reinterpret_cast<uint2*>(cur + own_c + mul24(lc, sBlk)) = make_uint2(f2u(M), ch);   // :780-783
+    if (accept) {
+      *reinterpret_cast<uint2*>(cur + own_c + mul24(lc, sBlk)) = make_uint2(f2u(M), ch);   // :780-783
 #pragma unroll
-    for (int a = LL - 1; a >= 1; --a) ah[a] = selv(accept, ah[a - 1], ah[a]);
-    ah[0] = selv(accept, ch, ah[0]);
-    asrc |= accept ? (unsigned long long)((sel << 3) | j) << (8 * lc) : 0ull;
-    lc += accept ? 1u : 0u;
+      for (int a = LL - 1; a >= 1; --a) ah[a] = opq(ah[a - 1]);
+      ah[0] = ch;
+      asrc |= (unsigned long long)((sel << 3) | j) << (8 * lc);
+      lc += 1u;
+    }
     // advance the popped list
 #pragma unroll
     for (int i = 0; i < NL; ++i) h[i] = selv(eq[i], ns, h[i]);

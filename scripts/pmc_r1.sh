@@ -2,7 +2,7 @@
 #   bash scripts/pmc_r1.sh <tag>      -> gpurun_out/<tag>_*  (copy the summaries into profiles/)
 export TMPDIR=/tmp
 TAG=${1:-r1}
-B="python3 bench.py --steps 1 --warmup 0 --slots 8 --reads-per-step 8 --no-cpu-baseline --check 0"
+B="python3 bench.py --steps 1 --warmup 0 --slots 8 --reads-per-step 8 --pool 8 --no-cpu-baseline --no-launch-events"
 run() { name=$1; shift; timeout 180 rocprofv3 "$@" --output-format csv -d gpurun_out/${TAG}_$name -- $B > gpurun_out/${TAG}_$name.log 2>&1 || echo "$name failed"; }
 run trace --kernel-trace --stats
 run sq1 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
