@@ -925,9 +925,12 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
     const bool accept = proceed && !isdup, reject = proceed && isdup;
     const uint32_t s7 = 7u * (lc - 1u - (uint32_t)q);          // (only meaningful when reject)
     const unsigned long long rec = (unsigned long long)(0x40u | (sel << 3) | j);
-    const bool full0 = reject && ((rej0 >> (s7 & 63u)) & 0x40u), full1 = reject && ((rej1 >> (s7 & 63u)) & 0x40u);
+    const bool full0 = reject && ((rej0 >> (s7 & 63u)) & 0x40u);
+    // two lists (flop target): a message sits once in each, so an entry has at most one match; a second one is a
+    // fingerprint collision and goes the same way as a third one among eight lists (reason 3, exact path)
+    const bool full1 = NL > 2 ? reject && ((rej1 >> (s7 & 63u)) & 0x40u) : full0;
     rej0 |= (reject && !full0) ? rec << (s7 & 63u) : 0ull;
-    rej1 |= (full0 && !full1) ? rec << (s7 & 63u) : 0ull;
+    if constexpr (NL > 2) rej1 |= (full0 && !full1) ? rec << (s7 & 63u) : 0ull;
     if (accept) {
       *reinterpret_cast<uint2*>(cur + own_c + mul24(lc, sBlk)) = make_uint2(f2u(M), ch);   // :780-783
 #pragma unroll
