@@ -677,6 +677,9 @@ namespace {
 #ifndef LVA_LAZY_ODD_MINWAVES
 #define LVA_LAZY_ODD_MINWAVES 8
 #endif
+#ifndef LVA_LAZY_ANCHOR_MINWAVES
+#define LVA_LAZY_ANCHOR_MINWAVES 1
+#endif
 #ifndef LVA_LAZY_GB
 #define LVA_LAZY_GB 2
 #endif
@@ -1323,7 +1326,7 @@ __device__ __forceinline__ bool lazy_output(const Geometry& g, const LazyCtx& x,
 // ANCHOR = false those at an odd step (workgroups of the other kind leave at once) -- the odd-step path keeps the
 // merge's small register footprint (no message in flight), the anchor path is the only one that pays for two hops.
 template <int LL, int P, bool ANCHOR>
-__global__ __launch_bounds__(8 * TS, ANCHOR ? 1 : LVA_LAZY_ODD_MINWAVES) void lva_step_lazy(StepArgs args, Geometry g, const DevCode* __restrict__ codes,
+__global__ __launch_bounds__(8 * TS, ANCHOR ? LVA_LAZY_ANCHOR_MINWAVES : LVA_LAZY_ODD_MINWAVES) void lva_step_lazy(StepArgs args, Geometry g, const DevCode* __restrict__ codes,
                                                      uint32_t* __restrict__ trellis, WorkHdr* __restrict__ hdr,
                                                      uint32_t* __restrict__ items) {
   __shared__ uint2 s_src[8 * LL * TS];
