@@ -680,6 +680,9 @@ namespace {
 #ifndef LVA_LAZY_ANCHOR_MINWAVES
 #define LVA_LAZY_ANCHOR_MINWAVES 1
 #endif
+#ifndef LVA_FIXUP_LAZY_GRID
+#define LVA_FIXUP_LAZY_GRID 4096   // workgroups (of four wavefronts) of lva_step_fixup_lazy
+#endif
 #ifndef LVA_LAZY_GB
 #define LVA_LAZY_GB 2
 #endif
@@ -2045,11 +2048,13 @@ int launch_step_fast(const StepArgs& a, const Geometry& g, const DevCode* codes,
     e = (int)hipGetLastError();
     if (e) return e;
     if (ev_mid && (e = (int)hipEventRecord((hipEvent_t)ev_mid, st))) return e;
+    // one target per wavefront and pass: the pass is a chain of dependent round trips, so more (mostly idle) wavefronts, not fewer
+    constexpr uint32_t kFixGrid = LVA_FIXUP_LAZY_GRID;
     switch (g.P) {
-      case 1: hipLaunchKernelGGL((lva_step_fixup_lazy<1>), dim3(256), dim3(256), 0, st, a, g, codes, trellis, hdr, items); break;
-      case 2: hipLaunchKernelGGL((lva_step_fixup_lazy<2>), dim3(256), dim3(256), 0, st, a, g, codes, trellis, hdr, items); break;
-      case 3: hipLaunchKernelGGL((lva_step_fixup_lazy<3>), dim3(256), dim3(256), 0, st, a, g, codes, trellis, hdr, items); break;
-      default: hipLaunchKernelGGL((lva_step_fixup_lazy<4>), dim3(256), dim3(256), 0, st, a, g, codes, trellis, hdr, items); break;
+      case 1: hipLaunchKernelGGL((lva_step_fixup_lazy<1>), dim3(kFixGrid), dim3(256), 0, st, a, g, codes, trellis, hdr, items); break;
+      case 2: hipLaunchKernelGGL((lva_step_fixup_lazy<2>), dim3(kFixGrid), dim3(256), 0, st, a, g, codes, trellis, hdr, items); break;
+      case 3: hipLaunchKernelGGL((lva_step_fixup_lazy<3>), dim3(kFixGrid), dim3(256), 0, st, a, g, codes, trellis, hdr, items); break;
+      default: hipLaunchKernelGGL((lva_step_fixup_lazy<4>), dim3(kFixGrid), dim3(256), 0, st, a, g, codes, trellis, hdr, items); break;
     }
     return (int)hipGetLastError();
   }
