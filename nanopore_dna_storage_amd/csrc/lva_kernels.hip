@@ -680,6 +680,9 @@ namespace {
 #ifndef LVA_LAZY_ANCHOR_MINWAVES
 #define LVA_LAZY_ANCHOR_MINWAVES 1
 #endif
+#ifndef LVA_REJ_SLOTS
+#define LVA_REJ_SLOTS 1
+#endif
 #ifndef LVA_FIXUP_LAZY_GRID
 #define LVA_FIXUP_LAZY_GRID 4096   // workgroups (of four wavefronts) of lva_step_fixup_lazy
 #endif
@@ -932,11 +935,15 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
     const uint32_t s7 = 7u * (lc - 1u - (uint32_t)q);          // (only meaningful when reject)
     const unsigned long long rec = (unsigned long long)(0x40u | (sel << 3) | j);
     const bool full0 = reject && ((rej0 >> (s7 & 63u)) & 0x40u);
-    // two lists (flop target): a message sits once in each, so an entry has at most one match; a second one is a
-    // fingerprint collision and goes the same way as a third one among eight lists (reason 3, exact path)
-    const bool full1 = NL > 2 ? reject && ((rej1 >> (s7 & 63u)) & 0x40u) : full0;
+    // Practically every duplicate pairs an entry of the stay list with an entry of ONE source list: the source lists of a
+    // target hardly ever share a message (instrumented oracle, scripts/merge_stats.py: 4-6 in 100 000 duplicate pops at
+    // m = 6 / 8 / 11, clean and noisy), so an accepted entry has one match at most.  A second one -- a message in three
+    // lists, or a fingerprint collision -- is reason 3: the exact path decides.
+    // (LVA_REJ_SLOTS=2 keeps a second slot per entry for eight-list merges, as until round 2.)
+    constexpr bool kSecond = LVA_REJ_SLOTS == 2 && NL > 2;
+    const bool full1 = kSecond ? reject && ((rej1 >> (s7 & 63u)) & 0x40u) : full0;
     rej0 |= (reject && !full0) ? rec << (s7 & 63u) : 0ull;
-    if constexpr (NL > 2) rej1 |= (full0 && !full1) ? rec << (s7 & 63u) : 0ull;
+    if constexpr (kSecond) rej1 |= (full0 && !full1) ? rec << (s7 & 63u) : 0ull;
     if (accept) {
       *reinterpret_cast<uint2*>(cur + own_c + mul24(lc, sBlk)) = make_uint2(f2u(M), ch);   // :780-783
 #pragma unroll

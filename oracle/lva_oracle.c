@@ -438,7 +438,10 @@ uint64_t lva_stats_targets, lva_stats_pops[8 * ST_MAXL + 1], lva_stats_accepted[
 uint64_t lva_stats_stay_depth[ST_MAXL + 1], lva_stats_src_depth[ST_MAXL + 1], lva_stats_src_rank_depth[8][ST_MAXL + 1];
 uint64_t lva_stats_src_pops_below[ST_MAXL + 1];     /* [K]: source-list pops with index < K */
 uint64_t lva_stats_src_pops_total, lva_stats_stay_pops_total, lva_stats_targets_src_within[ST_MAXL + 1];
+uint64_t lva_stats_dup_kind[3];                     /* duplicate pops: source vs source, popped from stay, matched a stay entry */
+uint64_t lva_stats_pops_noss[8 * ST_MAXL + 1];      /* pops per target if source-vs-source duplicates were skipped, not popped */
 void lva_oracle_stats_reset(void) {
+  memset(lva_stats_dup_kind, 0, sizeof lva_stats_dup_kind); memset(lva_stats_pops_noss, 0, sizeof lva_stats_pops_noss);
   lva_stats_targets = lva_stats_src_pops_total = lva_stats_stay_pops_total = 0;
   memset(lva_stats_pops, 0, sizeof lva_stats_pops); memset(lva_stats_accepted, 0, sizeof lva_stats_accepted);
   memset(lva_stats_stay_depth, 0, sizeof lva_stats_stay_depth); memset(lva_stats_src_depth, 0, sizeof lva_stats_src_depth);
@@ -446,11 +449,13 @@ void lva_oracle_stats_reset(void) {
   memset(lva_stats_src_pops_below, 0, sizeof lva_stats_src_pops_below);
   memset(lva_stats_targets_src_within, 0, sizeof lva_stats_targets_src_within);
 }
-static void lva_oracle_stats_record(uint32_t L, int np, const uint32_t *depth, uint32_t pops, uint32_t accepted) {
+static void lva_oracle_stats_record(uint32_t L, int np, const uint32_t *depth, uint32_t pops, uint32_t accepted, const uint32_t *dupk) {
   if (L >= ST_MAXL) return;
 #pragma omp critical(lva_stats)
   {
     lva_stats_targets++; lva_stats_pops[pops]++; lva_stats_accepted[accepted]++;
+    for (int q = 0; q < 3; q++) lva_stats_dup_kind[q] += dupk[q];
+    lva_stats_pops_noss[pops - dupk[0]]++;
     lva_stats_stay_depth[depth[0]]++; lva_stats_stay_pops_total += depth[0];
     uint32_t d[8]; int n = 0; uint32_t mx = 0;
     for (int i = 1; i < np; i++) {
@@ -562,7 +567,7 @@ int lva_oracle_decode(const lva_oracle_code *c, const float *post, uint32_t nblk
           heap_build(heap, hn);
           uint32_t l = 0;
 #ifdef LVA_ORACLE_STATS
-          uint32_t st_depth[MAX_PRED] = {0}, st_pops = 0; const int st_heads = hn;
+          uint32_t st_depth[MAX_PRED] = {0}, st_pops = 0, st_dupk[3] = {0, 0, 0}, st_acc_ps[ST_MAXL]; const int st_heads = hn;
 #endif
           while (hn > 0 && l < L) {
             hnode top = heap_pop(heap, &hn);
@@ -573,7 +578,15 @@ int lva_oracle_decode(const lva_oracle_code *c, const float *post, uint32_t nblk
             const size_t from = from_of[top.ps];
             msg_push(cand, prev->msg + (from * L + top.j) * W, W, pi->shift, pi->newbits);
             int dup = 0;
-            for (uint32_t a = 0; a < l && !dup; a++) dup = (memcmp(cm + a * W, cand, W * sizeof(uint32_t)) == 0);
+            for (uint32_t a = 0; a < l && !dup; a++) {
+              dup = (memcmp(cm + a * W, cand, W * sizeof(uint32_t)) == 0);
+#ifdef LVA_ORACLE_STATS
+              if (dup && L < ST_MAXL) st_dupk[top.ps == 0 ? 1 : (st_acc_ps[a] == 0 ? 2 : 0)]++;
+#endif
+            }
+#ifdef LVA_ORACLE_STATS
+            if (!dup && L < ST_MAXL) st_acc_ps[l] = top.ps;
+#endif
             if (!dup) { memcpy(cm + l * W, cand, W * sizeof(uint32_t)); cs[l] = top.score; l++; }
             if (top.j == L - 1) continue;                                          /* :788 */
             float nxt = prev->score[from * L + top.j + 1];
@@ -581,7 +594,7 @@ int lva_oracle_decode(const lva_oracle_code *c, const float *post, uint32_t nblk
               heap_push(heap, &hn, (hnode){nxt + pt_row[pi->row * 8 + pi->col], top.ps, top.j + 1});
           }
 #ifdef LVA_ORACLE_STATS
-          if (st_heads > 0) lva_oracle_stats_record(L, np, st_depth, st_pops, l);
+          if (st_heads > 0) lva_oracle_stats_record(L, np, st_depth, st_pops, l, st_dupk);
 #endif
           for (; l < L; l++) cs[l] = NEG;                                          /* :799 */
         }

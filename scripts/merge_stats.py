@@ -63,3 +63,21 @@ for K in (1, 2, 4, 8, 12, 16, 24, 32):
     if K <= L:
         print("K=%2d: %.1f%% of source-list pops have index < K; %.1f%% of targets never go beyond K in any source list"
               % (K, 100 * below[K] / max(sp, 1), 100 * within[K] / T))
+
+# pops per target, the iterations a 64-lane wavefront runs for them, and what skipping source-vs-source duplicates would change
+tot = pops.sum()
+print("pops per target: " + " ".join("%d:%.3f" % (i, pops[i] / tot) for i in range(min(len(pops), L + 12)) if pops[i] / tot >= 0.0005))
+
+
+def wave_max(hist, n=64):
+    cum = np.cumsum(hist) / hist.sum()
+    pm = np.diff(np.concatenate([[0.0], cum ** n]))
+    return (pm * np.arange(len(pm))).sum()
+
+
+dk = arr("lva_stats_dup_kind", 3); noss = arr("lva_stats_pops_noss", 8 * 65 + 1)
+print("mean pops %.2f, expected maximum over 64 independent targets %.2f" % ((pops * np.arange(len(pops))).sum() / tot, wave_max(pops)))
+print("duplicate pops per target %.2f: source vs source %.1f%%, popped from the stay list %.1f%%, source matching a stay entry %.1f%%" % (
+    dk.sum() / tot, 100 * dk[0] / dk.sum(), 100 * dk[1] / dk.sum(), 100 * dk[2] / dk.sum()))
+print("without the source-vs-source duplicates: mean pops %.2f, expected maximum over 64 targets %.2f" % (
+    (noss * np.arange(len(noss))).sum() / noss.sum(), wave_max(noss)))
