@@ -440,8 +440,13 @@ uint64_t lva_stats_src_pops_below[ST_MAXL + 1];     /* [K]: source-list pops wit
 uint64_t lva_stats_src_pops_total, lva_stats_stay_pops_total, lva_stats_targets_src_within[ST_MAXL + 1];
 uint64_t lva_stats_dup_kind[3];                     /* duplicate pops: source vs source, popped from stay, matched a stay entry */
 uint64_t lva_stats_pops_noss[8 * ST_MAXL + 1];      /* pops per target if source-vs-source duplicates were skipped, not popped */
+/* lineage: is a duplicate the SAME path seen twice (the stay entry was created from exactly that source entry, which has stayed in
+ * its own list since), or two different paths that spell the same message? */
+uint64_t lva_stats_dup_lineage[2];                  /* [0] same path, [1] different paths */
+uint64_t lva_stats_pops_nolin[8 * ST_MAXL + 1];     /* pops per target if same-path duplicates were dropped without a pop */
 void lva_oracle_stats_reset(void) {
   memset(lva_stats_dup_kind, 0, sizeof lva_stats_dup_kind); memset(lva_stats_pops_noss, 0, sizeof lva_stats_pops_noss);
+  memset(lva_stats_dup_lineage, 0, sizeof lva_stats_dup_lineage); memset(lva_stats_pops_nolin, 0, sizeof lva_stats_pops_nolin);
   lva_stats_targets = lva_stats_src_pops_total = lva_stats_stay_pops_total = 0;
   memset(lva_stats_pops, 0, sizeof lva_stats_pops); memset(lva_stats_accepted, 0, sizeof lva_stats_accepted);
   memset(lva_stats_stay_depth, 0, sizeof lva_stats_stay_depth); memset(lva_stats_src_depth, 0, sizeof lva_stats_src_depth);
@@ -456,6 +461,8 @@ static void lva_oracle_stats_record(uint32_t L, int np, const uint32_t *depth, u
     lva_stats_targets++; lva_stats_pops[pops]++; lva_stats_accepted[accepted]++;
     for (int q = 0; q < 3; q++) lva_stats_dup_kind[q] += dupk[q];
     lva_stats_pops_noss[pops - dupk[0]]++;
+    lva_stats_dup_lineage[0] += dupk[3]; lva_stats_dup_lineage[1] += dupk[4];
+    lva_stats_pops_nolin[pops - dupk[3]]++;
     lva_stats_stay_depth[depth[0]]++; lva_stats_stay_pops_total += depth[0];
     uint32_t d[8]; int n = 0; uint32_t mx = 0;
     for (int i = 1; i < np; i++) {
@@ -496,6 +503,14 @@ int lva_oracle_decode(const lva_oracle_code *c, const float *post, uint32_t nblk
     if (!buf[b].score || !buf[b].msg) return LVA_ORACLE_NOMEM;
     for (size_t i = 0; i < nstate * L; i++) buf[b].score[i] = NEG;                /* :616-619 */
   }
+#ifdef LVA_ORACLE_STATS
+  uint64_t *st_lin[2], *st_par[2]; uint32_t *st_pst[2];
+  for (int b = 0; b < 2; b++) {
+    st_lin[b] = (uint64_t *)calloc(nstate * L, sizeof(uint64_t)); st_par[b] = (uint64_t *)calloc(nstate * L, sizeof(uint64_t));
+    st_pst[b] = (uint32_t *)calloc(nstate * L, sizeof(uint32_t));
+    for (size_t i = 0; i < nstate * L; i++) st_lin[b][i] = (uint64_t)(i + 1);        /* time 0: every slot its own path */
+  }
+#endif
   /* valid-state mask (:624-630) */
   uint8_t *valid = (uint8_t *)malloc((size_t)npos * nconv);
   for (uint32_t p = 0; p < npos; p++)
@@ -523,6 +538,9 @@ int lva_oracle_decode(const lva_oracle_code *c, const float *post, uint32_t nblk
     uint32_t lo, hi;
     lva_oracle_band(c, t, nblk, max_deviation, band_fma, &lo, &hi);
     const float *pt_row = post + (size_t)t * 40;   /* [to_row 0..4][from 0..7], read_crf_post (:553-575) */
+#ifdef LVA_ORACLE_STATS
+    const int st_cb = cur == &buf[0] ? 0 : 1, st_pb = 1 - st_cb;
+#endif
     long p;
 #pragma omp parallel for schedule(dynamic)
     for (p = (long)lo; p < (long)hi; p++) {                                        /* :685-687 */
@@ -540,6 +558,9 @@ int lva_oracle_decode(const lva_oracle_code *c, const float *post, uint32_t nblk
           uint32_t *cm = cur->msg + st * L * W;
           if (pos == 0) {                                                          /* :706-713 */
             memcpy(cm, prev->msg + st * L * W, W * sizeof(uint32_t));
+#ifdef LVA_ORACLE_STATS
+            st_lin[st_cb][st * L] = st_lin[st_pb][st * L]; st_par[st_cb][st * L] = st_par[st_pb][st * L]; st_pst[st_cb][st * L] = st_pst[st_pb][st * L];
+#endif
             cs[0] = prev->score[st * L] + pt_row[pl[0].row * 8 + pl[0].col];
             for (uint32_t l = 1; l < L; l++) cs[l] = NEG;
             continue;
@@ -567,7 +588,7 @@ int lva_oracle_decode(const lva_oracle_code *c, const float *post, uint32_t nblk
           heap_build(heap, hn);
           uint32_t l = 0;
 #ifdef LVA_ORACLE_STATS
-          uint32_t st_depth[MAX_PRED] = {0}, st_pops = 0, st_dupk[3] = {0, 0, 0}, st_acc_ps[ST_MAXL]; const int st_heads = hn;
+          uint32_t st_depth[MAX_PRED] = {0}, st_pops = 0, st_dupk[5] = {0, 0, 0, 0, 0}, st_acc_ps[ST_MAXL]; const int st_heads = hn;
 #endif
           while (hn > 0 && l < L) {
             hnode top = heap_pop(heap, &hn);
@@ -581,11 +602,29 @@ int lva_oracle_decode(const lva_oracle_code *c, const float *post, uint32_t nblk
             for (uint32_t a = 0; a < l && !dup; a++) {
               dup = (memcmp(cm + a * W, cand, W * sizeof(uint32_t)) == 0);
 #ifdef LVA_ORACLE_STATS
-              if (dup && L < ST_MAXL) st_dupk[top.ps == 0 ? 1 : (st_acc_ps[a] == 0 ? 2 : 0)]++;
+              if (dup && L < ST_MAXL) {
+                st_dupk[top.ps == 0 ? 1 : (st_acc_ps[a] == 0 ? 2 : 0)]++;
+                /* the stay-side entry's parent (path and state it was created from) against the source-side entry */
+                const size_t ce = from * L + top.j, ae = st * L + a;
+                int same = 0;
+                if (top.ps != 0 && st_acc_ps[a] == 0) same = st_par[st_cb][ae] == st_lin[st_pb][ce] && st_pst[st_cb][ae] == (uint32_t)from;
+                else if (top.ps == 0 && st_acc_ps[a] != 0) same = st_par[st_pb][ce] == st_par[st_cb][ae] && st_pst[st_pb][ce] == st_pst[st_cb][ae];
+                st_dupk[same ? 3 : 4]++;
+                /* keep identities alive across the merge: a rejected stay entry hands its identity to the copy that beat it
+                 * (targets downstream know the message under that identity); a rejected source entry is the accepted
+                 * entry's twin from now on */
+                if (top.ps == 0) st_lin[st_cb][ae] = st_lin[st_pb][ce];
+                else { st_par[st_cb][ae] = st_lin[st_pb][ce]; st_pst[st_cb][ae] = (uint32_t)from; }
+              }
 #endif
             }
 #ifdef LVA_ORACLE_STATS
-            if (!dup && L < ST_MAXL) st_acc_ps[l] = top.ps;
+            if (!dup && L < ST_MAXL) {
+              st_acc_ps[l] = top.ps;
+              const size_t ce = from * L + top.j, ae = st * L + l;
+              if (top.ps == 0) { st_lin[st_cb][ae] = st_lin[st_pb][ce]; st_par[st_cb][ae] = st_par[st_pb][ce]; st_pst[st_cb][ae] = st_pst[st_pb][ce]; }
+              else { st_lin[st_cb][ae] = ((uint64_t)(t + 1) << 36) | (uint64_t)(ae + 1); st_par[st_cb][ae] = st_lin[st_pb][ce]; st_pst[st_cb][ae] = (uint32_t)from; }
+            }
 #endif
             if (!dup) { memcpy(cm + l * W, cand, W * sizeof(uint32_t)); cs[l] = top.score; l++; }
             if (top.j == L - 1) continue;                                          /* :788 */
