@@ -442,7 +442,7 @@ uint64_t lva_stats_dup_kind[3];                     /* duplicate pops: source vs
 uint64_t lva_stats_pops_noss[8 * ST_MAXL + 1];      /* pops per target if source-vs-source duplicates were skipped, not popped */
 /* lineage: is a duplicate the SAME path seen twice (the stay entry was created from exactly that source entry, which has stayed in
  * its own list since), or two different paths that spell the same message? */
-uint64_t lva_stats_dup_lineage[2];                  /* [0] same path, [1] different paths */
+uint64_t lva_stats_dup_lineage[3];                  /* [0] same path, [1] different paths, [2] identities equal but messages differ */
 uint64_t lva_stats_pops_nolin[8 * ST_MAXL + 1];     /* pops per target if same-path duplicates were dropped without a pop */
 void lva_oracle_stats_reset(void) {
   memset(lva_stats_dup_kind, 0, sizeof lva_stats_dup_kind); memset(lva_stats_pops_noss, 0, sizeof lva_stats_pops_noss);
@@ -461,7 +461,7 @@ static void lva_oracle_stats_record(uint32_t L, int np, const uint32_t *depth, u
     lva_stats_targets++; lva_stats_pops[pops]++; lva_stats_accepted[accepted]++;
     for (int q = 0; q < 3; q++) lva_stats_dup_kind[q] += dupk[q];
     lva_stats_pops_noss[pops - dupk[0]]++;
-    lva_stats_dup_lineage[0] += dupk[3]; lva_stats_dup_lineage[1] += dupk[4];
+    lva_stats_dup_lineage[0] += dupk[3]; lva_stats_dup_lineage[1] += dupk[4]; lva_stats_dup_lineage[2] += dupk[5];
     lva_stats_pops_nolin[pops - dupk[3]]++;
     lva_stats_stay_depth[depth[0]]++; lva_stats_stay_pops_total += depth[0];
     uint32_t d[8]; int n = 0; uint32_t mx = 0;
@@ -588,7 +588,7 @@ int lva_oracle_decode(const lva_oracle_code *c, const float *post, uint32_t nblk
           heap_build(heap, hn);
           uint32_t l = 0;
 #ifdef LVA_ORACLE_STATS
-          uint32_t st_depth[MAX_PRED] = {0}, st_pops = 0, st_dupk[5] = {0, 0, 0, 0, 0}, st_acc_ps[ST_MAXL]; const int st_heads = hn;
+          uint32_t st_depth[MAX_PRED] = {0}, st_pops = 0, st_dupk[6] = {0, 0, 0, 0, 0, 0}, st_acc_ps[ST_MAXL]; const int st_heads = hn;
 #endif
           while (hn > 0 && l < L) {
             hnode top = heap_pop(heap, &hn);
@@ -602,6 +602,13 @@ int lva_oracle_decode(const lva_oracle_code *c, const float *post, uint32_t nblk
             for (uint32_t a = 0; a < l && !dup; a++) {
               dup = (memcmp(cm + a * W, cand, W * sizeof(uint32_t)) == 0);
 #ifdef LVA_ORACLE_STATS
+              if (!dup && L < ST_MAXL) {   /* the converse: identities that say "twin" for two different messages (must never happen) */
+                const size_t ce = from * L + top.j, ae = st * L + a;
+                int idm = 0;
+                if (top.ps != 0 && st_acc_ps[a] == 0) idm = st_par[st_cb][ae] == st_lin[st_pb][ce] && st_pst[st_cb][ae] == (uint32_t)from;
+                else if (top.ps == 0 && st_acc_ps[a] != 0) idm = st_par[st_pb][ce] == st_par[st_cb][ae] && st_pst[st_pb][ce] == st_pst[st_cb][ae];
+                if (idm) st_dupk[5]++;
+              }
               if (dup && L < ST_MAXL) {
                 st_dupk[top.ps == 0 ? 1 : (st_acc_ps[a] == 0 ? 2 : 0)]++;
                 /* the stay-side entry's parent (path and state it was created from) against the source-side entry */

@@ -81,8 +81,9 @@ print("duplicate pops per target %.2f: source vs source %.1f%%, popped from the 
     dk.sum() / tot, 100 * dk[0] / dk.sum(), 100 * dk[1] / dk.sum(), 100 * dk[2] / dk.sum()))
 print("without the source-vs-source duplicates: mean pops %.2f, expected maximum over 64 targets %.2f" % (
     (noss * np.arange(len(noss))).sum() / noss.sum(), wave_max(noss)))
-dl = arr("lva_stats_dup_lineage", 2); nolin = arr("lva_stats_pops_nolin", 8 * 65 + 1)
+dl = arr("lva_stats_dup_lineage", 3); nolin = arr("lva_stats_pops_nolin", 8 * 65 + 1)
 print("duplicates that are the same path seen twice (the stay entry was made from that very source entry): %.2f%%; different paths, same message: %.2f%%" % (
-    100 * dl[0] / dl.sum(), 100 * dl[1] / dl.sum()))
+    100 * dl[0] / dl[:2].sum(), 100 * dl[1] / dl[:2].sum()))
+print("popped candidates whose identity named an accepted entry as twin although the messages differ: %d (must be 0)" % dl[2])
 print("if same-path duplicates were dropped without a pop: mean pops %.2f, expected maximum over 64 targets %.2f" % (
     (nolin * np.arange(len(nolin))).sum() / nolin.sum(), wave_max(nolin)))
