@@ -444,9 +444,14 @@ uint64_t lva_stats_pops_noss[8 * ST_MAXL + 1];      /* pops per target if source
  * its own list since), or two different paths that spell the same message? */
 uint64_t lva_stats_dup_lineage[3];                  /* [0] same path, [1] different paths, [2] identities equal but messages differ */
 uint64_t lva_stats_pops_nolin[8 * ST_MAXL + 1];     /* pops per target if same-path duplicates were dropped without a pop */
+/* the same with what a GPU lane would have: one twin word per entry (predecessor list, index) written at the merge, one
+ * forward map per list and step (old index -> new index), a step stamp per list (stale rows at the band edge give no twins) */
+uint64_t lva_stats_tw[3];                           /* [0] duplicate pops named by the twin words, [1] named although not a duplicate (must be 0), [2] all duplicate pops */
+uint64_t lva_stats_pops_notw[8 * ST_MAXL + 1];      /* pops per target without the duplicate pops the twin words name */
 void lva_oracle_stats_reset(void) {
   memset(lva_stats_dup_kind, 0, sizeof lva_stats_dup_kind); memset(lva_stats_pops_noss, 0, sizeof lva_stats_pops_noss);
   memset(lva_stats_dup_lineage, 0, sizeof lva_stats_dup_lineage); memset(lva_stats_pops_nolin, 0, sizeof lva_stats_pops_nolin);
+  memset(lva_stats_tw, 0, sizeof lva_stats_tw); memset(lva_stats_pops_notw, 0, sizeof lva_stats_pops_notw);
   lva_stats_targets = lva_stats_src_pops_total = lva_stats_stay_pops_total = 0;
   memset(lva_stats_pops, 0, sizeof lva_stats_pops); memset(lva_stats_accepted, 0, sizeof lva_stats_accepted);
   memset(lva_stats_stay_depth, 0, sizeof lva_stats_stay_depth); memset(lva_stats_src_depth, 0, sizeof lva_stats_src_depth);
@@ -463,6 +468,8 @@ static void lva_oracle_stats_record(uint32_t L, int np, const uint32_t *depth, u
     lva_stats_pops_noss[pops - dupk[0]]++;
     lva_stats_dup_lineage[0] += dupk[3]; lva_stats_dup_lineage[1] += dupk[4]; lva_stats_dup_lineage[2] += dupk[5];
     lva_stats_pops_nolin[pops - dupk[3]]++;
+    lva_stats_tw[0] += dupk[6]; lva_stats_tw[1] += dupk[7]; lva_stats_tw[2] += dupk[0] + dupk[1] + dupk[2];
+    lva_stats_pops_notw[pops - dupk[6]]++;
     lva_stats_stay_depth[depth[0]]++; lva_stats_stay_pops_total += depth[0];
     uint32_t d[8]; int n = 0; uint32_t mx = 0;
     for (int i = 1; i < np; i++) {
@@ -509,6 +516,11 @@ int lva_oracle_decode(const lva_oracle_code *c, const float *post, uint32_t nblk
     st_lin[b] = (uint64_t *)calloc(nstate * L, sizeof(uint64_t)); st_par[b] = (uint64_t *)calloc(nstate * L, sizeof(uint64_t));
     st_pst[b] = (uint32_t *)calloc(nstate * L, sizeof(uint32_t));
     for (size_t i = 0; i < nstate * L; i++) st_lin[b][i] = (uint64_t)(i + 1);        /* time 0: every slot its own path */
+  }
+  uint16_t *tw_w[2]; uint8_t *tw_f[2]; uint32_t *tw_stamp[2];
+  for (int b = 0; b < 2; b++) {
+    tw_w[b] = (uint16_t *)calloc(nstate * L, sizeof(uint16_t)); tw_f[b] = (uint8_t *)calloc(nstate * L, 1);
+    tw_stamp[b] = (uint32_t *)calloc(nstate, sizeof(uint32_t));
   }
 #endif
   /* valid-state mask (:624-630) */
@@ -588,7 +600,22 @@ int lva_oracle_decode(const lva_oracle_code *c, const float *post, uint32_t nblk
           heap_build(heap, hn);
           uint32_t l = 0;
 #ifdef LVA_ORACLE_STATS
-          uint32_t st_depth[MAX_PRED] = {0}, st_pops = 0, st_dupk[6] = {0, 0, 0, 0, 0, 0}, st_acc_ps[ST_MAXL]; const int st_heads = hn;
+          uint32_t st_depth[MAX_PRED] = {0}, st_pops = 0, st_dupk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_acc_ps[ST_MAXL]; const int st_heads = hn;
+          /* twin words of the own list, translated through the forward maps of the (fresh) source lists */
+          uint16_t tw_now[ST_MAXL], tw_new[ST_MAXL]; uint8_t tw_fnew[ST_MAXL], tw_dead_stay[ST_MAXL], tw_dead_src[MAX_PRED][ST_MAXL];
+          if (L < ST_MAXL) {
+            memset(tw_now, 0, sizeof tw_now); memset(tw_new, 0, sizeof tw_new); memset(tw_fnew, 0xFF, sizeof tw_fnew);
+            memset(tw_dead_stay, 0, sizeof tw_dead_stay); memset(tw_dead_src, 0, sizeof tw_dead_src);
+            if (tw_stamp[st_pb][from_of[0]] == t)
+              for (uint32_t j = 0; j < L; j++) {
+                const uint16_t v = tw_w[st_pb][from_of[0] * L + j];
+                if (!(v & 0x8000u)) continue;
+                const uint32_t ti = (v >> 8) & 0x7Fu, tj = v & 0xFFu;
+                if ((int)ti >= np || tw_stamp[st_pb][from_of[ti]] != t) continue;
+                const uint8_t f = tw_f[st_pb][from_of[ti] * L + tj];
+                if (f != 0xFF) tw_now[j] = (uint16_t)(0x8000u | ti << 8 | f);
+              }
+          }
 #endif
           while (hn > 0 && l < L) {
             hnode top = heap_pop(heap, &hn);
@@ -602,6 +629,10 @@ int lva_oracle_decode(const lva_oracle_code *c, const float *post, uint32_t nblk
             for (uint32_t a = 0; a < l && !dup; a++) {
               dup = (memcmp(cm + a * W, cand, W * sizeof(uint32_t)) == 0);
 #ifdef LVA_ORACLE_STATS
+              if (dup && L < ST_MAXL) {    /* twin words: the forward map and the refreshed twin of the accepted entry */
+                if (top.ps == 0) tw_fnew[top.j] = (uint8_t)a;
+                else tw_new[a] = (uint16_t)(0x8000u | top.ps << 8 | top.j);
+              }
               if (!dup && L < ST_MAXL) {   /* the converse: identities that say "twin" for two different messages (must never happen) */
                 const size_t ce = from * L + top.j, ae = st * L + a;
                 int idm = 0;
@@ -626,7 +657,15 @@ int lva_oracle_decode(const lva_oracle_code *c, const float *post, uint32_t nblk
 #endif
             }
 #ifdef LVA_ORACLE_STATS
+            if (L < ST_MAXL && (top.ps == 0 ? tw_dead_stay[top.j] : tw_dead_src[top.ps][top.j])) st_dupk[dup ? 6 : 7]++;
             if (!dup && L < ST_MAXL) {
+              if (top.ps == 0) {
+                tw_fnew[top.j] = (uint8_t)l; tw_new[l] = tw_now[top.j];
+                if (tw_now[top.j] & 0x8000u) tw_dead_src[(tw_now[top.j] >> 8) & 0x7Fu][tw_now[top.j] & 0xFFu] = 1;
+              } else {
+                tw_new[l] = (uint16_t)(0x8000u | top.ps << 8 | top.j);
+                for (uint32_t j0 = 0; j0 < L; j0++) if (tw_now[j0] == tw_new[l]) tw_dead_stay[j0] = 1;
+              }
               st_acc_ps[l] = top.ps;
               const size_t ce = from * L + top.j, ae = st * L + l;
               if (top.ps == 0) { st_lin[st_cb][ae] = st_lin[st_pb][ce]; st_par[st_cb][ae] = st_par[st_pb][ce]; st_pst[st_cb][ae] = st_pst[st_pb][ce]; }
@@ -641,6 +680,10 @@ int lva_oracle_decode(const lva_oracle_code *c, const float *post, uint32_t nblk
           }
 #ifdef LVA_ORACLE_STATS
           if (st_heads > 0) lva_oracle_stats_record(L, np, st_depth, st_pops, l, st_dupk);
+          if (L < ST_MAXL) {
+            for (uint32_t j = 0; j < L; j++) { tw_w[st_cb][st * L + j] = j < l ? tw_new[j] : 0; tw_f[st_cb][st * L + j] = tw_fnew[j]; }
+            tw_stamp[st_cb][st] = t + 1;
+          }
 #endif
           for (; l < L; l++) cs[l] = NEG;                                          /* :799 */
         }

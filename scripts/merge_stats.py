@@ -87,3 +87,7 @@ print("duplicates that are the same path seen twice (the stay entry was made fro
 print("popped candidates whose identity named an accepted entry as twin although the messages differ: %d (must be 0)" % dl[2])
 print("if same-path duplicates were dropped without a pop: mean pops %.2f, expected maximum over 64 targets %.2f" % (
     (nolin * np.arange(len(nolin))).sum() / nolin.sum(), wave_max(nolin)))
+tw = arr("lva_stats_tw", 3); notw = arr("lva_stats_pops_notw", 8 * 65 + 1)
+print("with one twin word per entry + one forward map per list and step (what a GPU lane would have): %.2f%% of the duplicate pops named, "
+      "%d named wrongly (must be 0)" % (100 * tw[0] / tw[2], tw[1]))
+print("without those pops: mean pops %.2f, expected maximum over 64 targets %.2f" % ((notw * np.arange(len(notw))).sum() / notw.sum(), wave_max(notw)))
