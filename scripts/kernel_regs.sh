@@ -1,7 +1,7 @@
 #!/bin/bash
 # Register / LDS / scratch usage of every kernel in lva_kernels.hip (from the gfx950 assembly metadata).
 cd "$(dirname "$0")/../nanopore_dna_storage_amd/csrc"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math --cuda-device-only -S -o /tmp/lva_k.s lva_kernels.hip || exit 1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math --cuda-device-only $1 -S -o /tmp/lva_k.s lva_kernels.hip || exit 1
 python3 - <<'PY'
 import re
 t = open('/tmp/lva_k.s').read()

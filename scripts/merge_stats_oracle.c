@@ -1,4 +1,8 @@
 /*
+ * merge_stats_oracle.c -- an instrumented COPY of oracle/lva_oracle.c for scripts/merge_stats.py (kernel design input:
+ * pops per target, duplicate lineage, twin words).  Not the oracle: the file that defines "correct" is oracle/lva_oracle.c,
+ * which carries none of the LVA_ORACLE_STATS bookkeeping below.  Built into /tmp by merge_stats.py only.
+ *
  * lva_oracle.c -- plain-C CPU oracle of the reference list-Viterbi decode path.
  *
  * TEST INFRASTRUCTURE ONLY (see lva_oracle.h).  Never linked into the product.
@@ -430,6 +434,59 @@ static inline void msg_push(uint32_t *dst, const uint32_t *src, uint32_t W, uint
   dst[0] |= newbits;
 }
 
+#ifdef LVA_ORACLE_STATS
+/* merge statistics for kernel design (scripts/merge_stats.py builds a copy of this file with
+ * -DLVA_ORACLE_STATS): how many heap pops a target needs, how deep each candidate list is consumed */
+#define ST_MAXL 65
+uint64_t lva_stats_targets, lva_stats_pops[8 * ST_MAXL + 1], lva_stats_accepted[ST_MAXL + 1];
+uint64_t lva_stats_stay_depth[ST_MAXL + 1], lva_stats_src_depth[ST_MAXL + 1], lva_stats_src_rank_depth[8][ST_MAXL + 1];
+uint64_t lva_stats_src_pops_below[ST_MAXL + 1];     /* [K]: source-list pops with index < K */
+uint64_t lva_stats_src_pops_total, lva_stats_stay_pops_total, lva_stats_targets_src_within[ST_MAXL + 1];
+uint64_t lva_stats_dup_kind[3];                     /* duplicate pops: source vs source, popped from stay, matched a stay entry */
+uint64_t lva_stats_pops_noss[8 * ST_MAXL + 1];      /* pops per target if source-vs-source duplicates were skipped, not popped */
+/* lineage: is a duplicate the SAME path seen twice (the stay entry was created from exactly that source entry, which has stayed in
+ * its own list since), or two different paths that spell the same message? */
+uint64_t lva_stats_dup_lineage[3];                  /* [0] same path, [1] different paths, [2] identities equal but messages differ */
+uint64_t lva_stats_pops_nolin[8 * ST_MAXL + 1];     /* pops per target if same-path duplicates were dropped without a pop */
+/* the same with what a GPU lane would have: one twin word per entry (predecessor list, index) written at the merge, one
+ * forward map per list and step (old index -> new index), a step stamp per list (stale rows at the band edge give no twins) */
+uint64_t lva_stats_tw[3];                           /* [0] duplicate pops named by the twin words, [1] named although not a duplicate (must be 0), [2] all duplicate pops */
+uint64_t lva_stats_pops_notw[8 * ST_MAXL + 1];      /* pops per target without the duplicate pops the twin words name */
+void lva_oracle_stats_reset(void) {
+  memset(lva_stats_dup_kind, 0, sizeof lva_stats_dup_kind); memset(lva_stats_pops_noss, 0, sizeof lva_stats_pops_noss);
+  memset(lva_stats_dup_lineage, 0, sizeof lva_stats_dup_lineage); memset(lva_stats_pops_nolin, 0, sizeof lva_stats_pops_nolin);
+  memset(lva_stats_tw, 0, sizeof lva_stats_tw); memset(lva_stats_pops_notw, 0, sizeof lva_stats_pops_notw);
+  lva_stats_targets = lva_stats_src_pops_total = lva_stats_stay_pops_total = 0;
+  memset(lva_stats_pops, 0, sizeof lva_stats_pops); memset(lva_stats_accepted, 0, sizeof lva_stats_accepted);
+  memset(lva_stats_stay_depth, 0, sizeof lva_stats_stay_depth); memset(lva_stats_src_depth, 0, sizeof lva_stats_src_depth);
+  memset(lva_stats_src_rank_depth, 0, sizeof lva_stats_src_rank_depth);
+  memset(lva_stats_src_pops_below, 0, sizeof lva_stats_src_pops_below);
+  memset(lva_stats_targets_src_within, 0, sizeof lva_stats_targets_src_within);
+}
+static void lva_oracle_stats_record(uint32_t L, int np, const uint32_t *depth, uint32_t pops, uint32_t accepted, const uint32_t *dupk) {
+  if (L >= ST_MAXL) return;
+#pragma omp critical(lva_stats)
+  {
+    lva_stats_targets++; lva_stats_pops[pops]++; lva_stats_accepted[accepted]++;
+    for (int q = 0; q < 3; q++) lva_stats_dup_kind[q] += dupk[q];
+    lva_stats_pops_noss[pops - dupk[0]]++;
+    lva_stats_dup_lineage[0] += dupk[3]; lva_stats_dup_lineage[1] += dupk[4]; lva_stats_dup_lineage[2] += dupk[5];
+    lva_stats_pops_nolin[pops - dupk[3]]++;
+    lva_stats_tw[0] += dupk[6]; lva_stats_tw[1] += dupk[7]; lva_stats_tw[2] += dupk[0] + dupk[1] + dupk[2];
+    lva_stats_pops_notw[pops - dupk[6]]++;
+    lva_stats_stay_depth[depth[0]]++; lva_stats_stay_pops_total += depth[0];
+    uint32_t d[8]; int n = 0; uint32_t mx = 0;
+    for (int i = 1; i < np; i++) {
+      d[n++] = depth[i]; lva_stats_src_depth[depth[i]]++; lva_stats_src_pops_total += depth[i];
+      if (depth[i] > mx) mx = depth[i];
+      for (uint32_t K = 0; K <= L; K++) lva_stats_src_pops_below[K] += depth[i] < K ? depth[i] : K;
+    }
+    for (uint32_t K = mx; K <= L; K++) lva_stats_targets_src_within[K]++;
+    for (int a = 0; a < n; a++) for (int b = a + 1; b < n; b++) if (d[b] > d[a]) { uint32_t t = d[a]; d[a] = d[b]; d[b] = t; }
+    for (int a = 0; a < n; a++) lva_stats_src_rank_depth[a][d[a]]++;
+  }
+}
+#endif
 
 int lva_oracle_decode(const lva_oracle_code *c, const float *post, uint32_t nblk, uint32_t L,
                       uint32_t max_deviation, int num_threads, uint32_t max_steps, int band_fma,
@@ -457,6 +514,19 @@ int lva_oracle_decode(const lva_oracle_code *c, const float *post, uint32_t nblk
     if (!buf[b].score || !buf[b].msg) return LVA_ORACLE_NOMEM;
     for (size_t i = 0; i < nstate * L; i++) buf[b].score[i] = NEG;                /* :616-619 */
   }
+#ifdef LVA_ORACLE_STATS
+  uint64_t *st_lin[2], *st_par[2]; uint32_t *st_pst[2];
+  for (int b = 0; b < 2; b++) {
+    st_lin[b] = (uint64_t *)calloc(nstate * L, sizeof(uint64_t)); st_par[b] = (uint64_t *)calloc(nstate * L, sizeof(uint64_t));
+    st_pst[b] = (uint32_t *)calloc(nstate * L, sizeof(uint32_t));
+    for (size_t i = 0; i < nstate * L; i++) st_lin[b][i] = (uint64_t)(i + 1);        /* time 0: every slot its own path */
+  }
+  uint16_t *tw_w[2]; uint8_t *tw_f[2]; uint32_t *tw_stamp[2];
+  for (int b = 0; b < 2; b++) {
+    tw_w[b] = (uint16_t *)calloc(nstate * L, sizeof(uint16_t)); tw_f[b] = (uint8_t *)calloc(nstate * L, 1);
+    tw_stamp[b] = (uint32_t *)calloc(nstate, sizeof(uint32_t));
+  }
+#endif
   /* valid-state mask (:624-630) */
   uint8_t *valid = (uint8_t *)malloc((size_t)npos * nconv);
   for (uint32_t p = 0; p < npos; p++)
@@ -484,6 +554,9 @@ int lva_oracle_decode(const lva_oracle_code *c, const float *post, uint32_t nblk
     uint32_t lo, hi;
     lva_oracle_band(c, t, nblk, max_deviation, band_fma, &lo, &hi);
     const float *pt_row = post + (size_t)t * 40;   /* [to_row 0..4][from 0..7], read_crf_post (:553-575) */
+#ifdef LVA_ORACLE_STATS
+    const int st_cb = cur == &buf[0] ? 0 : 1, st_pb = 1 - st_cb;
+#endif
     long p;
 #pragma omp parallel for schedule(dynamic)
     for (p = (long)lo; p < (long)hi; p++) {                                        /* :685-687 */
@@ -501,6 +574,9 @@ int lva_oracle_decode(const lva_oracle_code *c, const float *post, uint32_t nblk
           uint32_t *cm = cur->msg + st * L * W;
           if (pos == 0) {                                                          /* :706-713 */
             memcpy(cm, prev->msg + st * L * W, W * sizeof(uint32_t));
+#ifdef LVA_ORACLE_STATS
+            st_lin[st_cb][st * L] = st_lin[st_pb][st * L]; st_par[st_cb][st * L] = st_par[st_pb][st * L]; st_pst[st_cb][st * L] = st_pst[st_pb][st * L];
+#endif
             cs[0] = prev->score[st * L] + pt_row[pl[0].row * 8 + pl[0].col];
             for (uint32_t l = 1; l < L; l++) cs[l] = NEG;
             continue;
@@ -527,21 +603,92 @@ int lva_oracle_decode(const lva_oracle_code *c, const float *post, uint32_t nblk
           }
           heap_build(heap, hn);
           uint32_t l = 0;
+#ifdef LVA_ORACLE_STATS
+          uint32_t st_depth[MAX_PRED] = {0}, st_pops = 0, st_dupk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_acc_ps[ST_MAXL]; const int st_heads = hn;
+          /* twin words of the own list, translated through the forward maps of the (fresh) source lists */
+          uint16_t tw_now[ST_MAXL], tw_new[ST_MAXL]; uint8_t tw_fnew[ST_MAXL], tw_dead_stay[ST_MAXL], tw_dead_src[MAX_PRED][ST_MAXL];
+          if (L < ST_MAXL) {
+            memset(tw_now, 0, sizeof tw_now); memset(tw_new, 0, sizeof tw_new); memset(tw_fnew, 0xFF, sizeof tw_fnew);
+            memset(tw_dead_stay, 0, sizeof tw_dead_stay); memset(tw_dead_src, 0, sizeof tw_dead_src);
+            if (tw_stamp[st_pb][from_of[0]] == t)
+              for (uint32_t j = 0; j < L; j++) {
+                const uint16_t v = tw_w[st_pb][from_of[0] * L + j];
+                if (!(v & 0x8000u)) continue;
+                const uint32_t ti = (v >> 8) & 0x7Fu, tj = v & 0xFFu;
+                if ((int)ti >= np || tw_stamp[st_pb][from_of[ti]] != t) continue;
+                const uint8_t f = tw_f[st_pb][from_of[ti] * L + tj];
+                if (f != 0xFF) tw_now[j] = (uint16_t)(0x8000u | ti << 8 | f);
+              }
+          }
+#endif
           while (hn > 0 && l < L) {
             hnode top = heap_pop(heap, &hn);
+#ifdef LVA_ORACLE_STATS
+            st_depth[top.ps]++; st_pops++;
+#endif
             const pred_t *pi = &pl[top.ps];
             const size_t from = from_of[top.ps];
             msg_push(cand, prev->msg + (from * L + top.j) * W, W, pi->shift, pi->newbits);
             int dup = 0;
             for (uint32_t a = 0; a < l && !dup; a++) {
               dup = (memcmp(cm + a * W, cand, W * sizeof(uint32_t)) == 0);
+#ifdef LVA_ORACLE_STATS
+              if (dup && L < ST_MAXL) {    /* twin words: the forward map and the refreshed twin of the accepted entry */
+                if (top.ps == 0) tw_fnew[top.j] = (uint8_t)a;
+                else tw_new[a] = (uint16_t)(0x8000u | top.ps << 8 | top.j);
+              }
+              if (!dup && L < ST_MAXL) {   /* the converse: identities that say "twin" for two different messages (must never happen) */
+                const size_t ce = from * L + top.j, ae = st * L + a;
+                int idm = 0;
+                if (top.ps != 0 && st_acc_ps[a] == 0) idm = st_par[st_cb][ae] == st_lin[st_pb][ce] && st_pst[st_cb][ae] == (uint32_t)from;
+                else if (top.ps == 0 && st_acc_ps[a] != 0) idm = st_par[st_pb][ce] == st_par[st_cb][ae] && st_pst[st_pb][ce] == st_pst[st_cb][ae];
+                if (idm) st_dupk[5]++;
+              }
+              if (dup && L < ST_MAXL) {
+                st_dupk[top.ps == 0 ? 1 : (st_acc_ps[a] == 0 ? 2 : 0)]++;
+                /* the stay-side entry's parent (path and state it was created from) against the source-side entry */
+                const size_t ce = from * L + top.j, ae = st * L + a;
+                int same = 0;
+                if (top.ps != 0 && st_acc_ps[a] == 0) same = st_par[st_cb][ae] == st_lin[st_pb][ce] && st_pst[st_cb][ae] == (uint32_t)from;
+                else if (top.ps == 0 && st_acc_ps[a] != 0) same = st_par[st_pb][ce] == st_par[st_cb][ae] && st_pst[st_pb][ce] == st_pst[st_cb][ae];
+                st_dupk[same ? 3 : 4]++;
+                /* keep identities alive across the merge: a rejected stay entry hands its identity to the copy that beat it
+                 * (targets downstream know the message under that identity); a rejected source entry is the accepted
+                 * entry's twin from now on */
+                if (top.ps == 0) st_lin[st_cb][ae] = st_lin[st_pb][ce];
+                else { st_par[st_cb][ae] = st_lin[st_pb][ce]; st_pst[st_cb][ae] = (uint32_t)from; }
+              }
+#endif
             }
+#ifdef LVA_ORACLE_STATS
+            if (L < ST_MAXL && (top.ps == 0 ? tw_dead_stay[top.j] : tw_dead_src[top.ps][top.j])) st_dupk[dup ? 6 : 7]++;
+            if (!dup && L < ST_MAXL) {
+              if (top.ps == 0) {
+                tw_fnew[top.j] = (uint8_t)l; tw_new[l] = tw_now[top.j];
+                if (tw_now[top.j] & 0x8000u) tw_dead_src[(tw_now[top.j] >> 8) & 0x7Fu][tw_now[top.j] & 0xFFu] = 1;
+              } else {
+                tw_new[l] = (uint16_t)(0x8000u | top.ps << 8 | top.j);
+                for (uint32_t j0 = 0; j0 < L; j0++) if (tw_now[j0] == tw_new[l]) tw_dead_stay[j0] = 1;
+              }
+              st_acc_ps[l] = top.ps;
+              const size_t ce = from * L + top.j, ae = st * L + l;
+              if (top.ps == 0) { st_lin[st_cb][ae] = st_lin[st_pb][ce]; st_par[st_cb][ae] = st_par[st_pb][ce]; st_pst[st_cb][ae] = st_pst[st_pb][ce]; }
+              else { st_lin[st_cb][ae] = ((uint64_t)(t + 1) << 36) | (uint64_t)(ae + 1); st_par[st_cb][ae] = st_lin[st_pb][ce]; st_pst[st_cb][ae] = (uint32_t)from; }
+            }
+#endif
             if (!dup) { memcpy(cm + l * W, cand, W * sizeof(uint32_t)); cs[l] = top.score; l++; }
             if (top.j == L - 1) continue;                                          /* :788 */
             float nxt = prev->score[from * L + top.j + 1];
             if (nxt != NEG)
               heap_push(heap, &hn, (hnode){nxt + pt_row[pi->row * 8 + pi->col], top.ps, top.j + 1});
           }
+#ifdef LVA_ORACLE_STATS
+          if (st_heads > 0) lva_oracle_stats_record(L, np, st_depth, st_pops, l, st_dupk);
+          if (L < ST_MAXL) {
+            for (uint32_t j = 0; j < L; j++) { tw_w[st_cb][st * L + j] = j < l ? tw_new[j] : 0; tw_f[st_cb][st * L + j] = tw_fnew[j]; }
+            tw_stamp[st_cb][st] = t + 1;
+          }
+#endif
           for (; l < L; l++) cs[l] = NEG;                                          /* :799 */
         }
       }

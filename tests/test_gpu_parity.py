@@ -110,6 +110,36 @@ def test_work_list_overflow_falls_back_to_the_exact_step(oracle, monkeypatch):
     _compare(oracle, 6, 1, 60, 8, 20, reads, kernel=2)
 
 
+@pytest.mark.parametrize("kernel", [0, 4])
+@pytest.mark.parametrize("m,r,msg_len,L,md", [(6, 1, 60, 8, 20), (6, 1, 60, 2, 3), (8, 3, 44, 4, 20)])
+def test_work_list_overflow_in_lazy_mode_redoes_the_step_exactly(oracle, monkeypatch, kernel, m, r, msg_len, L, md):
+    """kernel mode 4 (the default for L = 2/4/8): a 4-entry work list overflows on every step of tie-heavy input; the
+    lazy fix-up then redoes the whole step on its exact path instead of refusing the batch (reference :762-796 decodes
+    any finite matrix).  Odd and even block counts, both orientations, slot turnover."""
+    monkeypatch.setenv("LVA_WORK_CAP", "4")
+    reads = synth.make_reads(m, r, msg_len, 5, seed0=31, rc_mode="odd", margin=3.0, quantum=0.25)
+    reads[1]["post"] = reads[1]["post"][:-1].copy()            # the other parity of the last step
+    with pkg.Decoder(m, r, msg_len, list_size=L, max_deviation=md, kernel=kernel, max_slots=2) as dec:
+        assert dec.profile()["kernel"] == 4
+    _compare(oracle, m, r, msg_len, L, md, reads, kernel=kernel, max_slots=2)
+
+
+def test_tie_dense_batch_through_default_slots(oracle):
+    """300 copies of the two tie-stress goldens through the DEFAULT slot count (m=6 L=8: 1024 slots, kernel mode 4):
+    tens of millions of fix-up targets per launch against a work list of 2^20 -- the overflow path at production
+    sizes; every list must equal the reference's (.list files made by the reference binary)."""
+    from golden_util import as_strings, load_case
+    for name in ("m6_r1_L8_ties", "m6_r5_L8_ties_rc"):
+        m, post, lines = load_case(name)
+        with pkg.Decoder(m["mem_conv"], m["rate"], m["msg_len"], list_size=m["list_size"], max_deviation=m["max_deviation"]) as dec:
+            assert dec.profile()["kernel"] == 4 and dec.profile()["slots"] == 1024
+            got = dec.decode([post] * 300, rc=[m["rc"]] * 300)
+            assert dec.profile()["fixup_states"] > 0
+        for g in got:
+            assert not isinstance(g, int), "decode error %r" % (g,)
+            assert as_strings(g[0]) == lines
+
+
 @pytest.mark.parametrize("md", [0, 1, 2])
 @pytest.mark.parametrize("kernel", [1, 2, 3])
 def test_tiny_bands(oracle, md, kernel):
