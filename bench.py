@@ -58,6 +58,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--cpu-reads", type=int, default=3, help="reads of the multi-thread reference sample")
     ap.add_argument("--no-launch-events", action="store_true", help="no per-launch HIP events (roofline from the span)")
+    ap.add_argument("--no-cross-check", action="store_true", help="skip the exact-kernel check of the last timed batch")
     ap.add_argument("--dump-lists", type=str, default="", help="rank 0 writes the gathered lists of the last step (npz)")
     return ap.parse_args(argv)
 
@@ -124,10 +125,7 @@ def main():
                       device=devno, max_slots=a.slots, kernel=a.kernel)
     slots = dec.profile()["slots"]
     if dist is not None and backend == "nccl":
-        import torch
-        devs = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
-        dist.all_gather(devs, torch.tensor([torch.cuda.current_device()], dtype=torch.int64, device="cuda"))
-        assert len({int(x.item()) for x in devs}) == world, "ranks share a GPU"
+        sharding.assert_one_gpu_per_rank(dist)
 
     # ---- the reads of this rank ------------------------------------------------------------------
     strong = a.total_reads > 0
@@ -157,17 +155,13 @@ def main():
         for bt in batches:
             bt["dev"], _ = dec.upload([x["post"] for x in bt["reads"]])
 
-    # ---- CPU leg, part 1: the single-thread reference sample runs beside the GPU leg (its own core) ----
+    # ---- CPU leg: set up here, run AFTER the timed region (nothing but the decoder's host thread works during it) ----
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle import oracle as O
         import tempfile
         cpu = dict(O=O, tmp=tempfile.mkdtemp(prefix="lva_bench_"))
-        if O.have_ref():
-            # read 5 of the pool: reverse complement, noisy (margin 3)
-            cpu["i1"] = 5 if len(batches[0]["reads"]) > 5 else 0
-            r1 = batches[0]["reads"][cpu["i1"]]
-            cpu["job1"] = RefJob(O, a, r1["post"], r1["rc"], 1, cpu["tmp"])
+        cpu["i1"] = 5 if len(batches[0]["reads"]) > 5 else 0      # read 5 of the pool: reverse complement, noisy (margin 3)
 
     def run(bt):
         if a.resident:
@@ -237,7 +231,8 @@ def main():
                        "h2d": "excluded (resident)" if a.resident else "included",
                        "h2d_ms_per_step": acc["h2d_ms"] / max(a.steps, 1), "h2d_bytes_per_step": acc["h2d_b"] / max(a.steps, 1),
                        "kernel": prof["kernel"], "fixup_states": acc["fix"], "fixup_reason": fixr,
-                       "gathered_lists": n_global, "mean_active_slots": acc["read_steps"] / max(acc["launches"], 1)},
+                       "gathered_lists": n_global, "mean_active_slots": acc["read_steps"] / max(acc["launches"], 1),
+                       "dist_backend": dist.get_backend() if dist is not None else None, "world": world},
         }
         use_events = acc["tl"] > 0
         dom_ms = acc["dom_ms"] if use_events else acc["span_ms"]
@@ -277,11 +272,28 @@ def main():
                      "note": "first..last step launch incl. slot init / final gather launches"},
             "end_to_end_achieved": (acc["alg"] / 1e9) / dt,
         }
+        # ---- every list of one timed batch against an independent exact kernel (mode 1: one thread per target, the
+        #      reference merge verbatim, no fingerprints, no lazy messages), outside the timed region ----
+        if not a.no_cross_check and prof["kernel"] != 1:
+            t1 = time.time()
+            with pkg.Decoder(a.mem_conv, a.rate, a.msg_len, list_size=a.list_size, max_deviation=a.max_deviation,
+                             device=devno, kernel=1) as dec1:
+                bt = batches[last_b]
+                want = dec1.decode_packed(bt["flat"], bt["off"], bt["rc"])
+            bad = [i for i, (g, w) in enumerate(zip(outs[last_b], want))
+                   if isinstance(g, int) or isinstance(w, int) or not (np.array_equal(g[0], w[0]) and
+                                                                    np.array_equal(g[1].view(np.uint32), w[1].view(np.uint32)))]
+            assert not bad, "lists of the timed batch differ from the exact kernel's for reads %r" % bad[:8]
+            res["config"]["cross_checked_reads"] = len(want)
+            res["config"]["cross_check"] = "all %d lists + scores of the last timed batch == kernel mode 1 (lva_step_exact), %.1f s" % (
+                len(want), time.time() - t1)
         if cpu is not None:
             O = cpu["O"]
             cores = a.cpu_threads or min(os.cpu_count() or 1, 16)
             checked = 0
             if O.have_ref():
+                r1 = batches[0]["reads"][cpu["i1"]]
+                cpu["job1"] = RefJob(O, a, r1["post"], r1["rc"], 1, cpu["tmp"])     # -t 1, beside the -t N sample below
                 # part 2: all cores (OpenMP -t), reads 0 (fwd, noisy), 1 (rc), 2 (fwd) of the pool, one after another
                 idxs = list(range(min(a.cpu_reads, len(batches[0]["reads"]))))
                 t_multi = 0.0
@@ -301,7 +313,7 @@ def main():
                 checked += 1
                 res["cpu_baseline_single_thread"] = dict(
                     value=1.0 / cpu["job1"].wall, unit="reads/s", cores=1, kind="reference",
-                    sample="1 read (rc, noisy, nblk=%d), -t 1, run beside the GPU leg on its own core; wall %.1f s"
+                    sample="1 read (rc, noisy, nblk=%d), -t 1, after the timed region (beside the -t N sample; run to run 85-135 s); wall %.1f s"
                            % (batches[0]["reads"][i1]["post"].shape[0], cpu["job1"].wall))
             else:
                 # the reference binary did not travel: time the plain-C restatement instead, and say so loudly

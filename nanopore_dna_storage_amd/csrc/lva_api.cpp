@@ -212,11 +212,11 @@ int lva_decoder_create(const lva_config* cfg, lva_decoder** out) {
   d->max_dev = cfg->max_deviation == LVA_MAX_DEVIATION_DEFAULT ? c.msg_len + (uint32_t)c.mem_conv + 1 : cfg->max_deviation;
   // kernel mode 4 ("lazy", list sizes 2, 4, 8): messages are materialised every second time step and carried as one-byte
   // back-pointers in between; two-hop chains reach one position further below the band, hence one more ring position
-  // Default (kernel 0) where it is the faster one: list sizes 2 / 4 / 8 with at most three message planes (m = 11 L = 8: +5 %,
-  // m = 8: +9 %; with four planes -- m = 14, msg_len 180 -- the anchor step's registers cost more than the bytes save: -10 %).
+  // Default (kernel 0) for list sizes 2 / 4 / 8 (m = 11 L = 8: +5 % over kernel 2, m = 8: +9 %; m = 14 with four message planes: +8 %
+  // since the anchor instance keeps one entry in flight there).
   const bool lazy_ok = (cfg->list_size == 2 || cfg->list_size == 4 || cfg->list_size == 8) && c.nconv >= 64;
   if (cfg->kernel == 4 && !lazy_ok) { delete d; return LVA_ERR_UNSUPPORTED; }
-  const bool lazy = cfg->kernel == 4 || (cfg->kernel == 0 && lazy_ok && c.msg_bits() <= 192);
+  const bool lazy = cfg->kernel == 4 || (cfg->kernel == 0 && lazy_ok);
   const uint64_t ring = std::min<uint64_t>(c.npos, 2ull * d->max_dev + (lazy ? 2 : 1));
   d->g = make_geometry(c.nconv, cfg->list_size, c.msg_bits(), (uint32_t)std::max<uint64_t>(ring, 1), lazy ? 1u : 0u);
   if (d->g.sPar >= ((uint64_t)1 << 32)) { delete d; return LVA_ERR_TOO_MANY_STATES; }

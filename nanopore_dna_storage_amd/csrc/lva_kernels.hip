@@ -689,8 +689,14 @@ namespace {
 #ifndef LVA_LAZY_GB
 #define LVA_LAZY_GB 2
 #endif
-#ifndef LVA_DEFER_TIE
-#define LVA_DEFER_TIE 0        // 1: equal scores on top are detected one pop later (no "last equal head" select chain in the loop)
+#ifndef LVA_LAZY_HOIST
+#define LVA_LAZY_HOIST 0       // 1: lva_step_lazy resolves its target and requests its stay list BEFORE staging (one round trip less behind the barrier)
+#endif
+#ifndef LVA_DEDUP_ASM
+#define LVA_DEDUP_ASM 0        // 1: the de-duplication scan of 8-entry lists as eight compares into eight SGPR pairs, then eight selects (no wait states)
+#endif
+#ifndef LVA_PUSH_VAR
+#define LVA_PUSH_VAR 0         // 1: lazy messages apply both moves with ONE funnel shift per word
 #endif
 #ifndef LVA_ACS_KERNEL
 #define LVA_ACS_KERNEL 1       // L == 1 runs lva_step_acs (256-thread workgroups) instead of lva_step_fast<1,P>
@@ -774,6 +780,14 @@ template <int W> __device__ __forceinline__ void push_bits(uint32_t (&m)[W], uin
   }
 }
 
+// m = (m << sh) | bits with a per-lane sh in 0..31: one funnel shift per word
+template <int W> __device__ __forceinline__ void push_var(uint32_t (&m)[W], uint32_t sh, uint32_t bits) {
+  const uint32_t back = 32u - sh;
+#pragma unroll
+  for (int w = W - 1; w >= 1; --w) m[w] = sh ? __builtin_amdgcn_alignbit(m[w], m[w - 1], back) : m[w];
+  m[0] = (m[0] << sh) | bits;
+}
+
 // Output phase of fast_merge for list entries [l_begin, l_end): gather the surviving messages from HBM, shift in the new
 // bits, store coalesced (:771-774, :780); every fingerprint match filed under an entry must be the same message --
 // false = a collision, the exact path redoes the target.
@@ -834,12 +848,12 @@ __device__ __forceinline__ bool fast_output(const Geometry& g, const uint32_t* _
 // target must be redone by the exact path.
 // The merge proper: decides the new list (scores and fingerprints are stored as it goes) and reports where every accepted
 // entry came from (asrc) and which fingerprint matches still have to be verified on the full message (rej0 / rej1).
-template <int LL, int NL>
+template <int LL, int NL, bool PRE = false>
 __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur,
                                                 const uint2* s_src, const float* s_post, uint32_t k, uint32_t c,
                                                 uint32_t sc, uint32_t own, uint32_t okmask, uint32_t fpc,
                                                 unsigned long long* o_asrc, unsigned long long* o_rej0, unsigned long long* o_rej1,
-                                                uint32_t* o_lc) {
+                                                uint32_t* o_lc, const uint2 (&pre)[LL]) {
   const float NEG = -INFINITY;
   const uint32_t sBlk = g.sBlk;
   const uint32_t row = k >= 4 ? 4u : k;
@@ -847,12 +861,15 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
   int why = 0;
 
   // the target's own ("stay") list lives in registers, transition score already added
+  // (pre: the caller requested its (score, fingerprint) pairs earlier)
   float st_s[LL]; uint32_t st_h[LL];
   const float add0 = s_post[row * 8 + k];
   if (okmask & 1u) {
 #pragma unroll
     for (int l = 0; l < LL; ++l) {
-      const uint2 v = *reinterpret_cast<const uint2*>(prev + own_c + l * sBlk);
+      uint2 v;
+      if constexpr (PRE) v = pre[l];
+      else v = *reinterpret_cast<const uint2*>(prev + own_c + l * sBlk);
       const float raw = u2f(v.x);
       st_s[l] = raw != NEG ? raw + add0 : NEG;
       if (raw != NEG && !(st_s[l] > NEG)) why = 2;       // non-finite sum: the exact path decides
@@ -889,9 +906,6 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
   // The loop body is written branch-free (selects) except for the store of an accepted entry:
   // lanes that are done keep running harmless iterations until the wavefront's last lane exits.
   bool go = why == 0;
-#if LVA_DEFER_TIE
-  float Mprev = __builtin_nanf("");
-#endif
   while (go) {                                                         // :764
     float M = h[0];
 #pragma unroll
@@ -904,19 +918,10 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
     uint32_t sel = NL - 1;
 #pragma unroll
     for (int i = NL - 2; i >= 0; --i) sel = eq[i] ? (uint32_t)i : sel;
-#if LVA_DEFER_TIE
-    // Equal scores on top are noticed ONE POP LATER: every list is sorted, so the value that replaces the popped head is
-    // <= M, and the next maximum equals M exactly when another head was equal to it (or the popped list's next entry
-    // is: flagged too, the exact path decides what needs no deciding).  What this iteration does with a wrongly chosen
-    // head is thrown away with the target; the last pop is checked behind the loop.
-    const bool two = M == Mprev;           // (Mprev = NaN before the first pop)
-    Mprev = M;
-#else
     uint32_t last = 0;                     // (the same test as lane-mask logic on the scalar unit: 0.4 % slower)
 #pragma unroll
     for (int i = 1; i < NL; ++i) last = eq[i] ? (uint32_t)i : last;
     const bool two = sel != last;
-#endif
     const bool alive = M > NEG;            // false: every list exhausted (heap empty)
     const bool proceed = alive && !two;
     const uint32_t j = (ptr >> (4 * sel)) & 15u;
@@ -943,8 +948,23 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
     }
     // de-duplicate on fingerprints (:778-779): position q in ah <-> accepted entry lc-1-q
     int q = -1;
+#if LVA_DEDUP_ASM
+    if constexpr (LL == 8) {
+      // eight compares into eight SGPR pairs, then the selects: no select waits for the compare in front of it
+      // (the compiler's schedule reuses one pair and pays two wait states per entry)
+      unsigned long long c0, c1, c2, c3, c4, c5, c6, c7;
+      asm("v_cmp_ne_u32_e64 %1, %9, %17\n\tv_cmp_ne_u32_e64 %2, %10, %17\n\tv_cmp_ne_u32_e64 %3, %11, %17\n\tv_cmp_ne_u32_e64 %4, %12, %17\n\t"
+          "v_cmp_ne_u32_e64 %5, %13, %17\n\tv_cmp_ne_u32_e64 %6, %14, %17\n\tv_cmp_ne_u32_e64 %7, %15, %17\n\tv_cmp_ne_u32_e64 %8, %16, %17\n\t"
+          "v_cndmask_b32_e64 %0, 7, %0, %1\n\tv_cndmask_b32_e64 %0, 6, %0, %2\n\tv_cndmask_b32_e64 %0, 5, %0, %3\n\tv_cndmask_b32_e64 %0, 4, %0, %4\n\t"
+          "v_cndmask_b32_e64 %0, 3, %0, %5\n\tv_cndmask_b32_e64 %0, 2, %0, %6\n\tv_cndmask_b32_e64 %0, 1, %0, %7\n\tv_cndmask_b32_e64 %0, 0, %0, %8"
+          : "+v"(q), "=&s"(c7), "=&s"(c6), "=&s"(c5), "=&s"(c4), "=&s"(c3), "=&s"(c2), "=&s"(c1), "=&s"(c0)
+          : "v"(ah[7]), "v"(ah[6]), "v"(ah[5]), "v"(ah[4]), "v"(ah[3]), "v"(ah[2]), "v"(ah[1]), "v"(ah[0]), "v"(ch));
+    } else
+#endif
+    {
 #pragma unroll
-    for (int a = LL - 1; a >= 0; --a) q = ah[a] == ch ? a : q;
+      for (int a = LL - 1; a >= 0; --a) q = ah[a] == ch ? a : q;
+    }
     const bool isdup = q >= 0 && (uint32_t)q < lc;
     const bool accept = proceed && !isdup, reject = proceed && isdup;
     const uint32_t s7 = 7u * (lc - 1u - (uint32_t)q);          // (only meaningful when reject)
@@ -974,14 +994,6 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
     why = (alive && two) ? 1 : ((proceed && bad) ? 2 : ((full0 && full1) ? 3 : 0));
     go = proceed && why == 0 && lc < (uint32_t)LL;
   }
-#if LVA_DEFER_TIE
-  if (why == 0) {                          // the last pop: was another head equal to it?
-    float M = h[0];
-#pragma unroll
-    for (int i = 1; i < NL; ++i) M = fmaxf(M, h[i]);
-    if (M == Mprev && M > NEG) why = 1;
-  }
-#endif
   if (why) return why;
 
   // unused tail of the list (:799)
@@ -999,7 +1011,8 @@ __device__ __forceinline__ int fast_merge(const Geometry& g, const uint32_t* __r
                                            uint32_t nb, uint32_t fpc, uint32_t np_dst, uint32_t np_src) {
   unsigned long long asrc, rej0, rej1;
   uint32_t lc;
-  const int why = fast_merge_core<LL, NL>(g, prev, cur, s_src, s_post, k, c, sc, own, okmask, fpc, &asrc, &rej0, &rej1, &lc);
+  const uint2 none[LL] = {};
+  const int why = fast_merge_core<LL, NL>(g, prev, cur, s_src, s_post, k, c, sc, own, okmask, fpc, &asrc, &rej0, &rej1, &lc, none);
   if (why) return why;
   return fast_output<LL, P>(g, prev, cur, k, c, cp, own, src, sh, nb, np_dst, np_src, asrc, rej0, rej1, lc, 0, LL) ? 0 : 4;
 }
@@ -1247,8 +1260,12 @@ __device__ __forceinline__ void lazy_message(const LazyCtx& x, uint32_t i, uint3
 #pragma unroll
     for (int w = 0; w < 2 * P; ++w) mw[w] = 0;
   }
+#if LVA_PUSH_VAR
+  push_var<2 * P>(mw, s1 + s2, (n1 << s2) | (s2 ? x.nb_p : 0u));
+#else
   push_bits<2 * P>(mw, s1, n1);
   push_bits<2 * P>(mw, s2, x.nb_p);
+#endif
 }
 
 __device__ __forceinline__ void lazy_ctx(const DevCode& cd, const Geometry& g, const SlotStep& ss, const uint32_t* slot_base, uint32_t pos,
@@ -1321,7 +1338,10 @@ __device__ __forceinline__ bool lazy_output(const Geometry& g, const LazyCtx& x,
     return good;
   }
   // ---- anchor step: two hops to the stored message, both moves applied, stored coalesced; LVA_LAZY_GB entries in flight ----
-  constexpr int GB = LL >= LVA_LAZY_GB ? LVA_LAZY_GB : LL;
+  // (four message planes: one entry in flight -- 8 more message registers would cost the anchor instance a wavefront per SIMD;
+  //  measured at m=14: 4.91 against 4.69 reads/s)
+  constexpr int GBW = P >= 4 ? 1 : LVA_LAZY_GB;
+  constexpr int GB = LL >= GBW ? GBW : LL;
 #pragma unroll
   for (int l0 = 0; l0 < LL; l0 += GB) {
     uint32_t m[GB][2 * P], mv[GB];                         // mv: the moves to apply, packed (s1 | n1 << 2 | s2 << 4)
@@ -1343,8 +1363,12 @@ __device__ __forceinline__ bool lazy_output(const Geometry& g, const LazyCtx& x,
     for (int u = 0; u < GB; ++u) {
       const int l = l0 + u;
       if ((uint32_t)l < lc) {
+#if LVA_PUSH_VAR
+        push_var<2 * P>(m[u], (mv[u] & 3u) + (mv[u] >> 4), (((mv[u] >> 2) & 3u) << (mv[u] >> 4)) | ((mv[u] >> 4) ? x.nb_p : 0u));
+#else
         push_bits<2 * P>(m[u], mv[u] & 3u, (mv[u] >> 2) & 3u);
         push_bits<2 * P>(m[u], mv[u] >> 4, x.nb_p);
+#endif
         store_msg<P>(mout + x.own + l * x.sBlk + x.pw, x.N, x.c, x.np_p, m[u]);
         if ((uint32_t)(rej0 >> (7 * l)) & 0x40u) verify(l, m[u]);
       }
@@ -1396,6 +1420,18 @@ __global__ __launch_bounds__(8 * TS, ANCHOR ? LVA_LAZY_ANCHOR_MINWAVES : LVA_LAZ
     return;
   }
 
+#if LVA_LAZY_HOIST
+  // this thread's target and its stay list first: the loads travel with the staging loads instead of behind the barrier
+  TileTarget t;
+  const bool has_target = tile_target<TS>(cd, g, ss, pos, tile, tid, &t);
+  uint2 stv[LL];
+#pragma unroll
+  for (int l = 0; l < LL; ++l) stv[l] = make_uint2(kNegInfBits, 0u);
+  if (has_target && (t.ok & 1u)) {
+#pragma unroll
+    for (int l = 0; l < LL; ++l) stv[l] = *reinterpret_cast<const uint2*>(prev + t.own + 2 * t.c + l * g.sBlk);
+  }
+#endif
   // ---- stage the (score, fingerprint) pairs of 64 source conv states (and, for an anchor step, their back-pointer bytes) ----
   const uint32_t src = (uint32_t)((uint64_t)((pos - 1) % g.R) * 8 * g.sCrf);
   for (uint32_t chunk = tid; chunk < 8u * LL * (TS / 2); chunk += 8u * TS) {
@@ -1415,8 +1451,15 @@ __global__ __launch_bounds__(8 * TS, ANCHOR ? LVA_LAZY_ANCHOR_MINWAVES : LVA_LAZ
   if (tid < 40) s_post[tid] = ss.post_row[tid];
   __syncthreads();
 
+#if LVA_LAZY_HOIST
+  if (!has_target) return;
+  constexpr bool kPre = true;
+#else
   TileTarget t;
   if (!tile_target<TS>(cd, g, ss, pos, tile, tid, &t)) return;
+  constexpr bool kPre = false;
+  const uint2 stv[LL] = {};
+#endif
   // an anchor step needs the back-pointer bytes of its own (stay) list: requested now, used after the merge
   unsigned long long own_bp = 0;
   if (anchor && ss.t != 0 && (t.ok & 1u)) {
@@ -1427,8 +1470,8 @@ __global__ __launch_bounds__(8 * TS, ANCHOR ? LVA_LAZY_ANCHOR_MINWAVES : LVA_LAZ
   }
   unsigned long long asrc = 0, rej0 = 0, rej1 = 0;
   uint32_t lc = 0;
-  int why = t.k < 4 ? fast_merge_core<LL, 8>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &rej1, &lc)
-                    : fast_merge_core<LL, 2>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &rej1, &lc);
+  int why = t.k < 4 ? fast_merge_core<LL, 8, kPre>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &rej1, &lc, stv)
+                    : fast_merge_core<LL, 2, kPre>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &rej1, &lc, stv);
   if (!why) {
     LazyCtx x;
     lazy_ctx(cd, g, ss, slot_base, pos, t.c, t.cp, t.k, t.own, &x);

@@ -18,6 +18,9 @@ file OUT_PREFIX_i per read (:85-90, max-deviation 20), and the info file "readid
 The original flags are kept (those describing the unavailable input side are accepted and ignored).
 
 Beyond the reference:
+  --chunk C  the manifest is decoded C reads at a time (default 4096): bounded host memory, and every finished
+             chunk's list files are on disk (each written to a temporary name and renamed), so a killed run
+             resumes from its last finished chunk
   --resume   skip reads whose OUT_PREFIX_i already exists (the reference re-runs by computing the read-ids
              that are not done yet, util/extra/pick_new_reads.py:11-18; one output file per read is its
              checkpoint)
@@ -56,6 +59,7 @@ def build_parser():
     p.add_argument("--device", type=int, default=0)
     p.add_argument("--resume", action="store_true")
     p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--chunk", type=int, default=4096, help="reads decoded (and written) per pass over the manifest")
     return p
 
 
@@ -77,56 +81,61 @@ def read_manifest(args):
     return rows
 
 
-def decode_rows(args, rows, device):
-    """the per-read work of generate_decoded_lists.py:50-98 for `rows` on one GPU
+def decode_rows(args, rows, dec):
+    """the per-read work of generate_decoded_lists.py:50-98 for `rows` on one GPU (`dec`: this rank's Decoder)
     -> (results: one of list | negative error code | BARCODE_FAILURE per row, located: {row index: window dict})"""
     min_len = args.mem_conv + args.msg_len + 1
     results = [BARCODE_FAILURE] * len(rows)
     located = {}
     if not rows:
         return results, located
-    with Decoder(args.mem_conv, args.rate_conv, args.msg_len, list_size=args.list_size,
-                 max_deviation=args.max_deviation, device=device) as dec:
-        # rows without a window: basecall + barcode search + decode on the device (:68-89)
-        todo = [i for i, r in enumerate(rows) if r[3] is None]
-        if todo:
-            chain = dec.decode_with_barcodes([helper.read_post_file(rows[i][2]) for i in todo],
-                                             args.start_barcode, args.end_barcode)
-            for i, (loc, res) in zip(todo, chain):
-                located[i] = dict(start_pos=int(loc["start_pos"]), end_pos=int(loc["end_pos"]), rc=bool(loc["rc"]))
-                if res is not None:
-                    results[i] = res
-        # rows with a window from an earlier search (:76, :84)
-        keep = [i for i, r in enumerate(rows) if r[3] is not None and not (r[3] == -1 or r[4] - r[3] + 1 < min_len)]
-        if keep:
-            posts = [helper.truncate_post(helper.read_post_file(rows[i][2]), rows[i][3], rows[i][4]) for i in keep]
-            for i, res in zip(keep, dec.decode(posts, rc=[rows[i][5] for i in keep])):
+    # rows without a window: basecall + barcode search + decode on the device (:68-89)
+    todo = [i for i, r in enumerate(rows) if r[3] is None]
+    if todo:
+        chain = dec.decode_with_barcodes([helper.read_post_file(rows[i][2]) for i in todo],
+                                         args.start_barcode, args.end_barcode)
+        for i, (loc, res) in zip(todo, chain):
+            located[i] = dict(start_pos=int(loc["start_pos"]), end_pos=int(loc["end_pos"]), rc=bool(loc["rc"]))
+            if res is not None:
                 results[i] = res
+    # rows with a window from an earlier search (:76, :84)
+    keep = [i for i, r in enumerate(rows) if r[3] is not None and not (r[3] == -1 or r[4] - r[3] + 1 < min_len)]
+    if keep:
+        posts = [helper.truncate_post(helper.read_post_file(rows[i][2]), rows[i][3], rows[i][4]) for i in keep]
+        for i, res in zip(keep, dec.decode(posts, rc=[rows[i][5] for i in keep])):
+            results[i] = res
     return results, located
 
 
+def write_list_file(path, msgs):
+    """one decoded list, written to a temporary name and moved into place: a run killed in the middle never leaves
+    a truncated OUT_PREFIX_i that --resume would take for a finished read"""
+    tmp = path + ".tmp%d" % os.getpid()
+    with open(tmp, "w") as f:
+        for row in msgs:
+            f.write("".join("1" if b else "0" for b in row) + "\n")
+    os.replace(tmp, path)
+
+
 def run(args, out=sys.stdout, dist=None, device=None, coll_dev=None):
+    """The manifest is walked in chunks of --chunk reads (bounded host memory: a chunk's posterior matrices are the only
+    ones loaded; per-chunk progress: every finished chunk's list files are on disk, which is what --resume picks up
+    after a crash).  Per chunk: strided shards over the ranks, decode, gather on rank 0, rank 0 writes the files."""
     rows = read_manifest(args)
     n = len(rows)
     done = [args.resume and os.path.exists(args.out_prefix + "_" + str(i)) for i in range(n)]
     work = [i for i in range(n) if not done[i]]
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
-    shards = sharding.shard_strided(len(work), world)
-    mine = [work[int(j)] for j in shards[rank]]
-    res, loc = decode_rows(args, [rows[i] for i in mine], args.device if device is None else device)
-    loc = {mine[j]: v for j, v in loc.items()}
-    if dist is not None:
-        res = sharding.gather_results(res, shards, args.list_size, args.msg_len, dist=dist, device=coll_dev)
-        locs = [None] * world if rank == 0 else None
-        dist.gather_object(loc, locs, dst=0)
-        if rank != 0:
-            return 0
-        loc = {k: v for d in locs for k, v in d.items()}
-    results = {work[j]: r for j, r in enumerate(res)}
+    chunk = max(1, int(args.chunk))
     written = 0
-    with open(args.info_file, "w") as f_info:
-        for i, (rid, ref, path, s, e, rc) in enumerate(rows):
+    cursor = 0                                  # rank 0: rows [0, cursor) have been reported
+    f_info = open(args.info_file, "w") if rank == 0 else None
+
+    def report(upto, results, loc):
+        nonlocal cursor, written
+        for i in range(cursor, upto):
+            rid, ref = rows[i][0], rows[i][1]
             print("i:", i, file=out); print(rid, file=out); print(ref, file=out)
             f_info.write(rid + "\t" + ref + "\n")
             if done[i]:
@@ -139,10 +148,30 @@ def run(args, out=sys.stdout, dist=None, device=None, coll_dev=None):
                 if r == BARCODE_FAILURE:
                     print("Failure in barcode removing.", file=out)
                 continue       # (other codes: the reference decoder aborts, no output file, on such a read)
-            with open(args.out_prefix + "_" + str(i), "w") as f:
-                for row in r[0]:
-                    f.write("".join("1" if b else "0" for b in row) + "\n")
+            write_list_file(args.out_prefix + "_" + str(i), r[0])
             written += 1
+        cursor = max(cursor, upto)
+        f_info.flush()
+
+    with Decoder(args.mem_conv, args.rate_conv, args.msg_len, list_size=args.list_size, max_deviation=args.max_deviation,
+                 device=args.device if device is None else device) as dec:
+        for k in range(0, len(work), chunk):
+            part = work[k:k + chunk]
+            shards = sharding.shard_strided(len(part), world)
+            mine = [part[int(j)] for j in shards[rank]]
+            res, loc = decode_rows(args, [rows[i] for i in mine], dec)
+            loc = {mine[j]: v for j, v in loc.items()}
+            if dist is not None:
+                res = sharding.gather_results(res, shards, args.list_size, args.msg_len, dist=dist, device=coll_dev)
+                locs = [None] * world if rank == 0 else None
+                dist.gather_object(loc, locs, dst=0)
+                if rank == 0:
+                    loc = {kk: v for d in locs for kk, v in d.items()}
+            if rank == 0:
+                report(part[-1] + 1, {part[j]: r for j, r in enumerate(res)}, loc)
+    if rank == 0:
+        report(n, {}, {})
+        f_info.close()
     return written
 
 
@@ -155,6 +184,8 @@ def main(argv=None):
     dist, rank, world, device, coll_dev = sharding.init_rank()
     if rank == 0:
         print(args)
+        if dist is not None:
+            print("ranks %d backend %s" % (world, dist.get_backend()))
     if dist is None:
         run(args)
     else:

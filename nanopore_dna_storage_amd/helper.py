@@ -1,9 +1,10 @@
 """Host-side helpers around the decode path, mirroring the parts of the reference's helper.py
 that sit next to the decoder call (helper.py:305): post truncation (helper.py:211-224), reverse
 complement (:227-229), bit/byte conversions (:365-369) and the CRC-8 / index filter over a
-decoded list (:371-388).  Everything else in the reference's helper.py (signal simulation,
-fast5 writing, barcode search, RS glue) needs scrappy / fast5_research / schifra and is out of
-scope.
+decoded list (:371-388), and the two end-to-end drivers `encode` (:231-273) and `simulate_and_decode`
+(:275-350) on top of the RS outer code (rs_code.py), the convolutional encoder (lva_encode) and the list
+decoder.  The reference's signal simulation and fast5 writing need scrappy / fast5_research and are
+replaced by synth.py's posterior generator.
 
 CRC-8: the reference calls the PyPI module `crc8` (unpinned, install_python_packages.sh:3), which
 is not installable here.  Its algorithm -- polynomial x^8+x^2+x+1 (0x07), init 0, no reflection,
@@ -164,6 +165,104 @@ def decode_list_CRC_index(decoded_msg_list, bytes_per_oligo, num_oligos, pad):
         if index < num_oligos:
             return index, payload, entry
     return None, None, None
+
+
+def encode(data_file, oligo_file, bytes_per_oligo, RS_redundancy, conv_m, conv_r, pad=False, device=0, out=None):
+    """helper.py:231-273, same arguments and files: data_file -> segments of bytes_per_oligo bytes (padded with b'0')
+    -> RS outer code over the segments (rs_code.MainEncoder: csrc/rs_kernels.hip) -> per oligo PRP(index) | payload |
+    CRC-8 [| pad bit] written to oligo_file + '.conv_input' -> convolutional code (lva_encode, the `-m encode` of the
+    reference binary) -> oligo_file, one ACGT string per line.  -> the list of oligo strings."""
+    import sys
+    from . import rs_code
+    from .decoder import encode as conv_encode
+    out = sys.stdout if out is None else out
+    assert bytes_per_oligo % 2 == 0
+    assert conv_m in [6, 8, 11, 14]
+    assert conv_r in [1, 2, 3, 4, 5, 7]
+    with open(data_file, "rb") as f:
+        data = f.read()
+    data_size = len(data)
+    data_size_padded = math.ceil(data_size / bytes_per_oligo) * bytes_per_oligo
+    msg_len, num_oligos_data, num_oligos_RS, num_oligos = compute_parameters(bytes_per_oligo, RS_redundancy, data_size_padded, pad)
+    data_padded = data.ljust(data_size_padded, b"0")
+    segmented_data = [data_padded[i * bytes_per_oligo:(i + 1) * bytes_per_oligo] for i in range(num_oligos_data)]
+    with_rs = rs_code.MainEncoder(segmented_data, num_oligos_RS, device=device) if num_oligos_RS else segmented_data
+    bit_strings = [attach_index_crc(index, oligo, pad) for index, oligo in enumerate(with_rs)]
+    with open(oligo_file + ".conv_input", "w") as f:
+        for b in bit_strings:
+            f.write(b + "\n")
+    msgs = np.array([[int(ch) for ch in b] for b in bit_strings], dtype=np.uint8)
+    bases = conv_encode(conv_m, conv_r, msg_len, msgs)
+    oligos = ["".join("ACGT"[int(x)] for x in row) for row in np.atleast_2d(bases)]
+    with open(oligo_file, "w") as f:
+        for o in oligos:
+            f.write(o + "\n")
+    print("oligo_len", len(oligos[0]), file=out)
+    print("writing rate (bits per base):", data_size * 8 / (len(oligos[0]) * num_oligos), file=out)
+    return oligos
+
+
+def simulate_and_decode(oligo_file, decoded_data_file, num_reads, data_file_size, bytes_per_oligo, RS_redundancy, conv_m, conv_r,
+                        pad=False, syn_sub_prob=0.005, syn_del_prob=0.005, syn_ins_prob=0.0005, deepsimdwell=False, num_thr=16,
+                        list_size=1, seed=None, margin=6.0, device=0, out=None, decoder=None):
+    """helper.py:275-350, same arguments: num_reads times pick a random oligo and orientation, pass it through the
+    substitution / deletion / insertion channel, turn it into a posterior matrix, decode a list of list_size candidates,
+    take the first candidate whose CRC-8 checks and whose index is in range (the first payload seen for an index stands,
+    :326-329), then RS-decode the indices that arrived and write the first data_file_size bytes.
+    The signal simulator and the basecaller network of the reference (scrappy, flappie) are replaced by
+    synth.posteriors_from_bases (`margin`: how far the true transition stands out); all reads are decoded in ONE batch
+    on the GPU instead of one decoder process per read.  seed: numpy seed (the reference draws from the global state).
+    -> dict(num_attempted, num_success, num_unique, decoded bytes)."""
+    import sys
+    from . import rs_code, synth
+    from .decoder import Decoder
+    out = sys.stdout if out is None else out
+    data_size_padded = math.ceil(data_file_size / bytes_per_oligo) * bytes_per_oligo
+    msg_len, num_oligos_data, num_oligos_RS, num_oligos = compute_parameters(bytes_per_oligo, RS_redundancy, data_size_padded, pad)
+    with open(oligo_file) as f:
+        oligo_list = [ln.rstrip("\n") for ln in f.readlines()]
+    print("oligo_len", len(oligo_list[0]), file=out)
+    rng = np.random.default_rng(seed)
+    posts, rcs = [], []
+    for _ in range(num_reads):
+        oligo = oligo_list[int(rng.integers(len(oligo_list)))]
+        rc = bool(rng.integers(2))
+        if rc:
+            oligo = reverse_complement(oligo)
+        seq = synth.mutate(synth.bases_from_str(oligo), rng, syn_sub_prob, syn_del_prob, syn_ins_prob)
+        posts.append(synth.posteriors_from_bases(seq, rng, margin=margin))
+        rcs.append(rc)
+    own = decoder is None
+    dec = Decoder(conv_m, conv_r, msg_len, list_size=list_size, max_deviation=20, device=device) if own else decoder
+    try:
+        results = dec.decode(posts, rc=rcs)
+    finally:
+        if own:
+            dec.close()
+    decoded_dict = {}
+    num_success = 0
+    for res in results:
+        if isinstance(res, (int, np.integer)):
+            continue                                   # (the reference decoder aborts on such a read: no list)
+        lst = ["".join("1" if b else "0" for b in row) for row in res[0]]
+        index, payload_bytes, _ = decode_list_CRC_index(lst, bytes_per_oligo, num_oligos, pad)
+        if index is not None:
+            num_success += 1
+            if index not in decoded_dict:
+                decoded_dict[index] = payload_bytes
+    print("num_attempted:", num_reads, file=out)
+    print("num success:", num_success, file=out)
+    print("num_unique", len(decoded_dict), file=out)
+    decoded_list = [[k, decoded_dict[k]] for k in decoded_dict]
+    if num_oligos_RS:
+        RS_decoded_list = rs_code.MainDecoder(decoded_list, num_oligos_RS, num_oligos, device=device)
+    else:
+        RS_decoded_list = [decoded_dict.get(i, b"0" * bytes_per_oligo) for i in range(num_oligos_data)]
+    assert len(RS_decoded_list) == num_oligos_data
+    decoded_data = b"".join(RS_decoded_list)[:data_file_size]
+    with open(decoded_data_file, "wb") as f:
+        f.write(decoded_data)
+    return dict(num_attempted=num_reads, num_success=num_success, num_unique=len(decoded_dict), data=decoded_data)
 
 
 def hamming(a, b):

@@ -78,7 +78,7 @@ def gather_results(local_results, shards, list_size, msg_len, dist=None, device=
     global read order, the other ranks return None.  `shards` = the same list of index arrays on
     every rank.  `device`: where the collective's tensors live ("cuda" for nccl/RCCL, None = CPU for gloo)."""
     import torch
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force_dist()):
         out = [None] * sum(len(s) for s in shards)
         for idx, item in zip(shards[0], local_results):
             out[int(idx)] = item
@@ -117,7 +117,7 @@ def decode_sharded(decode_fn, posts, rc, list_size, msg_len, dist=None, device=N
     decode_fn(posts_subset, rc_subset) -> list of results (this rank's Decoder.decode).
     Every rank passes the same posts/rc (entries of other ranks' shards may be None when `shards` is
     given); rank 0 gets the full result list in input order, other ranks get None."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force_dist()):
         return decode_fn(posts, rc)
     world, rank = dist.get_world_size(), dist.get_rank()
     if shards is None:
@@ -136,6 +136,25 @@ def free_port():
         return s.getsockname()[1]
 
 
+def force_dist():
+    """LVA_FORCE_DIST=1: a single rank still creates its process group and runs every collective of the multi-rank
+    path (group of one) -- how the RCCL branch is exercised on a 1-GPU box."""
+    return os.environ.get("LVA_FORCE_DIST", "") not in ("", "0")
+
+
+def assert_one_gpu_per_rank(dist, device="cuda"):
+    """every rank of an RCCL group must own its GPU: all_gather of (host, device ordinal) pairs, all distinct"""
+    import zlib
+    import torch
+    world = dist.get_world_size()
+    me = torch.tensor([zlib.crc32(socket.gethostname().encode()), torch.cuda.current_device()], dtype=torch.int64, device=device)
+    got = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(got, me)
+    pairs = {(int(x[0].item()), int(x[1].item())) for x in got}
+    assert len(pairs) == world, "ranks share a GPU: %r" % (sorted(pairs),)
+    return sorted(pairs)
+
+
 def launch_ranks(script, argv, nproc, env=None, capture=False, module=False):
     """Run `script argv...` (`python -m script argv...` when module=True) as `nproc` ranks of one node through torch.distributed.run (one process
     per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) and wait for them.
@@ -143,8 +162,9 @@ def launch_ranks(script, argv, nproc, env=None, capture=False, module=False):
     The caller must not have initialised the GPU: the ranks are fresh child processes started with
     subprocess (never an exec of the current process).  -> the launcher's exit code (and its stdout when
     capture=True)."""
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(nproc)),
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port())] + (["-m"] if module else []) + [script] + list(argv)
+    # --standalone: torchrun picks the rendezvous port itself (no bind-close-reuse race between concurrent launches)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(int(nproc))] + (["-m"] if module else []) + [script] + list(argv)
     e = dict(os.environ if env is None else env)
     e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this driver
     e.setdefault("OMP_NUM_THREADS", "1")
@@ -162,8 +182,12 @@ def init_rank(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1:
+    if world == 1 and not force_dist():
         return None, 0, 1, local, None
+    if world == 1:                                        # LVA_FORCE_DIST: a group of one, started without a launcher
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("LOCAL_RANK", "0")
     import torch
     import torch.distributed as dist
     backend = backend or os.environ.get("LVA_DIST_BACKEND", "nccl")

@@ -58,7 +58,8 @@ def main():
             res = sharding.decode_sharded(dec.decode, posts, rc, ls, ml, dist=dist, device=coll_dev, shards=shards)
     if rank == 0:
         c, mm, s = sharding.pack_results(res, ls, ml)
-        np.savez(out_path, counts=c, msgs=mm, scores=s, world=world)
+        np.savez(out_path, counts=c, msgs=mm, scores=s, world=world, grouped=int(dist is not None),
+                 backend=(dist.get_backend() if dist is not None else ""))
     else:
         assert res is None
     if dist is not None:

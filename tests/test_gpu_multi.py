@@ -66,6 +66,35 @@ def test_bench_starts_its_own_ranks(tmp_path):
         assert j["config"]["h2d"] == "included" and j["config"]["h2d_bytes_per_step"] > 0
 
 
+def test_rccl_branch_on_one_gpu(tmp_path):
+    """LVA_FORCE_DIST=1: a single rank runs init_process_group("nccl", device_id=...), the one-GPU-per-rank all_gather,
+    the max all_reduce of the step time and gather_results on cuda tensors -- every RCCL call of the N > 1 path, on
+    the one GPU of this box; lists equal those of the plain run."""
+    j1, z1 = _bench(["--gpus", "1"] + SMALL, {"LVA_FORCE_DIST": "1"}, tmp_path, "forced")
+    j0, z0 = _bench(["--gpus", "1"] + SMALL, {}, tmp_path, "plain")
+    assert j1["config"]["dist_backend"] == "nccl" and j1["config"]["world"] == 1 and j1["n_gpus"] == 1
+    assert j0["config"]["dist_backend"] is None
+    for k in ("counts", "msgs"):
+        assert np.array_equal(z1[k], z0[k])
+    assert np.array_equal(z1["scores"].view(np.uint32), z0["scores"].view(np.uint32))
+    # the rank worker with the REAL decoder through the forced nccl group
+    out = str(tmp_path / "g1.npz")
+    env = dict(os.environ, LVA_FORCE_DIST="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LVA_DIST_BACKEND"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(HERE, "_rank_worker.py"), out, "gpu", "7", "6", "1", "60", "4"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    z = np.load(out)
+    assert str(z["backend"]) == "nccl" and int(z["world"]) == 1
+    reads = [synth.make_read(6, 1, 60, seed=7000 + i, rc=bool(i & 1), margin=3.0 if i % 3 == 0 else 6.0) for i in range(7)]
+    with pkg.Decoder(6, 1, 60, list_size=4, max_deviation=20) as dec:
+        want = dec.decode([x["post"] for x in reads], rc=[x["rc"] for x in reads])
+    c, mm, s = sharding.pack_results(want, 4, 60)
+    assert np.array_equal(z["counts"], c) and np.array_equal(z["msgs"], mm)
+    assert np.array_equal(z["scores"].view(np.uint32), s.view(np.uint32))
+
+
 def test_bench_weak_mode_cycles_distinct_batches(tmp_path):
     j, z = _bench(["--gpus", "1", "--steps", "3", "--warmup", "0", "--reads-per-step", "5", "--pool", "12", "--mem-conv", "6",
                    "--rate", "1", "--msg-len", "60", "--list-size", "4", "--no-cpu-baseline", "--slots", "2"], {}, tmp_path, "weak")
@@ -96,7 +125,8 @@ def _manifest(tmp_path, n=5):
 
 
 def test_generate_decoded_lists_two_ranks_and_resume(tmp_path):
-    """--gpus 2: the driver starts its own rank processes, rank 0 gathers the lists and writes every file;
+    """--gpus 2 --chunk 2: the driver starts its own rank processes and walks the manifest two reads at a time (three
+    gathers for five reads); rank 0 gathers the lists and writes every file (temporary name + rename);
     --resume: list files that exist are left alone (the reference's per-read checkpoint, pick_new_reads.py:11-18)."""
     man, msgs, flags = _manifest(tmp_path)
     d1, d2 = tmp_path / "one", tmp_path / "two"
@@ -108,13 +138,24 @@ def test_generate_decoded_lists_two_ranks_and_resume(tmp_path):
     p1 = subprocess.run(base + ["--out_prefix", str(d1 / "list"), "--info_file", str(d1 / "info.txt")], env=env,
                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p1.returncode == 0, p1.stderr[-2000:]
-    p2 = subprocess.run(base + ["--out_prefix", str(d2 / "list"), "--info_file", str(d2 / "info.txt"), "--gpus", "2"], env=env,
+    p2 = subprocess.run(base + ["--out_prefix", str(d2 / "list"), "--info_file", str(d2 / "info.txt"), "--gpus", "2", "--chunk", "2"], env=env,
                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert p2.returncode == 0, p2.stderr[-2000:]
     assert (d1 / "info.txt").read_text() == (d2 / "info.txt").read_text()
     for i, msg in enumerate(msgs):
         a, b = (d1 / ("list_%d" % i)).read_text(), (d2 / ("list_%d" % i)).read_text()
         assert a == b and a.split()[0] == msg
+    # the same manifest through a forced RCCL group of one: gather_results on cuda tensors + gather_object
+    d3 = tmp_path / "forced"
+    d3.mkdir()
+    env3 = dict(env, LVA_FORCE_DIST="1")
+    env3.pop("LVA_DIST_BACKEND")
+    p4 = subprocess.run(base + ["--out_prefix", str(d3 / "list"), "--info_file", str(d3 / "info.txt")], env=env3,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p4.returncode == 0, p4.stderr[-2000:]
+    assert "backend nccl" in p4.stdout
+    for i in range(len(msgs)):
+        assert (d1 / ("list_%d" % i)).read_text() == (d3 / ("list_%d" % i)).read_text()
     # resume: a marker in place of list_1 survives, a deleted list_2 comes back
     (d1 / "list_1").write_text("kept\n")
     keep2 = (d1 / "list_2").read_text()

@@ -113,3 +113,25 @@ def test_bench_parent_refuses_mismatched_group(tmp_path):
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert p.returncode != 0 and "launcher started 1 ranks" in p.stderr
+
+
+def test_forced_group_of_one_runs_the_collectives(tmp_path):
+    """LVA_FORCE_DIST=1: one rank, started WITHOUT a launcher, still creates its process group (gloo here, nccl on
+    the GPU box) and goes through gather_results' collective branch; result equals the plain single-process one."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    import _rank_worker as W
+    out = str(tmp_path / "g1.npz")
+    env = dict(os.environ, LVA_DIST_BACKEND="gloo", LVA_FORCE_DIST="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(here, "_rank_worker.py"), out, "fake", "9"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    z = np.load(out)
+    assert int(z["world"]) == 1 and int(z["grouped"]) == 1
+    posts, rc = W.fake_posts(9)
+    c, m, s = sharding.pack_results(W.fake_decode(posts, rc), W.L, W.MSG)
+    assert np.array_equal(z["counts"], c) and np.array_equal(z["msgs"], m) and np.array_equal(z["scores"], s)
