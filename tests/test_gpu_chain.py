@@ -24,8 +24,9 @@ def _data_file(tmp_path, n=1000, seed=5):
 
 def test_encode_simulate_and_decode_round_trip(tmp_path):
     """experiment-7 shape in small (supplement 5.2: m=8, rate 3/4, 18 bytes per oligo, 30 % RS, list 8): 1 kB file,
-    72 oligos, 160 noisy reads (margin 3, substitutions / deletions / insertions at simulate_and_decode's defaults),
-    about one oligo in ten never sequenced -> the decoded file equals the input"""
+    72 oligos, 400 reads at a signal-to-noise ratio where about half of the reads decode (margin 4.3 at rate 3/4; margin 3
+    decodes none, margin 5 all), substitutions / deletions / insertions at simulate_and_decode's defaults, some oligos
+    never recovered -> the outer code fills them in and the decoded file equals the input"""
     infile = _data_file(tmp_path)
     out = io.StringIO()
     oligos = helper.encode(data_file=infile, oligo_file=infile + ".oligos", bytes_per_oligo=18, RS_redundancy=0.3, conv_m=8,
@@ -33,12 +34,12 @@ def test_encode_simulate_and_decode_round_trip(tmp_path):
     assert len(oligos) == 56 + 16 and "oligo_len" in out.getvalue()
     conv_in = open(infile + ".oligos.conv_input").read().split()
     assert len(conv_in) == 72 and all(len(b) == 12 + 144 + 8 for b in conv_in)
-    r = helper.simulate_and_decode(oligo_file=infile + ".oligos", decoded_data_file=infile + ".decoded", num_reads=160,
+    r = helper.simulate_and_decode(oligo_file=infile + ".oligos", decoded_data_file=infile + ".decoded", num_reads=400,
                                    data_file_size=1000, bytes_per_oligo=18, RS_redundancy=0.3, conv_m=8, conv_r=3, pad=False,
-                                   list_size=8, seed=77, margin=3.0, out=io.StringIO())
+                                   list_size=8, seed=77, margin=4.3, out=io.StringIO())
     assert filecmp.cmp(infile, infile + ".decoded", shallow=False)
-    assert r["num_unique"] < 72                       # some oligos never arrived: the outer code filled them in
-    assert r["num_success"] <= r["num_attempted"] == 160
+    assert 56 <= r["num_unique"] <= 72
+    assert 0.25 * 400 < r["num_success"] < 0.95 * 400 and r["num_attempted"] == 400     # erasures AND successes: the regime the list + CRC + RS chain is for
 
 
 def test_round_trip_with_pad_bit_and_m6(tmp_path):
@@ -46,7 +47,7 @@ def test_round_trip_with_pad_bit_and_m6(tmp_path):
     infile = _data_file(tmp_path, n=300, seed=9)
     helper.encode(infile, infile + ".oligos", 12, 1, 6, 1, pad=False, out=io.StringIO())
     helper.simulate_and_decode(infile + ".oligos", infile + ".decoded", 120, 300, 12, 1, 6, 1, pad=False, list_size=4, seed=3,
-                               margin=4.0, out=io.StringIO())
+                               margin=4.5, out=io.StringIO())
     assert filecmp.cmp(infile, infile + ".decoded", shallow=False)
 
 
@@ -65,7 +66,7 @@ def test_list_files_to_error_rates_and_outer_decode(tmp_path):
         o = oligos[int(rng.integers(n_oligos))]
         rc = bool(rng.integers(2))
         seq = synth.bases_from_str(helper.reverse_complement(o) if rc else o)
-        post = synth.posteriors_from_bases(synth.mutate(seq, rng, 0.004, 0.0085, 0.0005), rng, margin=3.5)
+        post = synth.posteriors_from_bases(synth.mutate(seq, rng, 0.004, 0.0085, 0.0005), rng, margin=5.0)
         p = tmp_path / ("r%d.post" % i)
         post.tofile(p)
         rows.append("read%d\tref\t%s\t0\t%d\t%d" % (i, p, post.shape[0] - 1, int(rc)))
@@ -80,7 +81,7 @@ def test_list_files_to_error_rates_and_outer_decode(tmp_path):
         ["--list_size", "8", "--decoded_lists_dir", str(lists_dir), "--conv_input_file", infile + ".oligos.conv_input",
          "--bytes_per_oligo", "18"], out=out)
     assert t["num_reads"] == n_reads and t["num_correct"] + t["num_erasure_CRC_index"] + t["num_error_CRC_index"] == n_reads
-    assert t["num_correct"] > 0.8 * n_reads and "num_correct: %d" % t["num_correct"] in out.getvalue()
+    assert t["num_correct"] > 0.7 * n_reads and "num_correct: %d" % t["num_correct"] in out.getvalue()
     out = io.StringIO()
     ok = decode_RS_from_decoded_lists.main(
         ["--num_trials", "3", "--list_size", "8", "--num_reads_total", str(n_reads), "--num_reads_to_use", str(int(0.8 * n_reads)),
