@@ -696,34 +696,16 @@ namespace {
 #ifndef LVA_LAZY_GB
 #define LVA_LAZY_GB 2
 #endif
-#ifndef LVA_LAZY_HOIST
-#define LVA_LAZY_HOIST 0       // 1: lva_step_lazy resolves its target and requests its stay list BEFORE staging (one round trip less behind the barrier)
-#endif
-#ifndef LVA_DEDUP_ASM
-#define LVA_DEDUP_ASM 0        // 1: the de-duplication scan of 8-entry lists as eight compares into eight SGPR pairs, then eight selects (no wait states)
-#endif
 #ifndef LVA_PUSH_VAR
 #define LVA_PUSH_VAR 1         // 1: message bits are pushed with ONE funnel shift per word (lazy messages: both moves at once; +4 % at m=11 L=8)
-#endif
-#ifndef LVA_ANCHOR_NOBRANCH
-#define LVA_ANCHOR_NOBRANCH 0  // 1: the anchor instance's output phase requests its message pieces without control flow
-#endif
-#ifndef LVA_ANCHOR_GBN
-#define LVA_ANCHOR_GBN 4       // entries in flight there (<= 3 message planes)
-#endif
-#ifndef LVA_BIG_NOBRANCH
-#define LVA_BIG_NOBRANCH 0     // 1: the big-list kernel's output phase requests everything of GB entries without control flow
-#endif
-#ifndef LVA_VERIFY_PASS
-#define LVA_VERIFY_PASS 0      // 1: lazy kernels confirm fingerprint matches in a pass of their own, both messages requested together
-#endif
-#ifndef LVA_ACS_PPW
-#define LVA_ACS_PPW 1          // L == 1, m <= 8: band positions per workgroup (lva_step_acs_multi)
 #endif
 #ifndef LVA_ACS_KERNEL
 #define LVA_ACS_KERNEL 1       // L == 1 runs lva_step_acs (256-thread workgroups) instead of lva_step_fast<1,P>
 #endif
-constexpr uint32_t TS = 64;      // source conv states per workgroup tile (workgroup = 8*TS threads); 32 measured 10 % slower
+#ifndef LVA_TS
+#define LVA_TS 64
+#endif
+constexpr uint32_t TS = LVA_TS;  // source conv states per workgroup tile (workgroup = 8*TS threads); 32 measured 10 % slower
 
 // An opaque copy of a register value.  Selecting between two elements of a local array,
 // `c ? a[i] : a[j]`, is folded by LLVM into a load from a selected ADDRESS, which pins the whole
@@ -768,30 +750,6 @@ template <int P> __device__ __forceinline__ void load_msg(const uint32_t* __rest
       }
     }
   }
-}
-// The same load WITHOUT control flow: both pieces are requested whatever np is (the second one from the first one's address
-// when the position has no third / fourth plane), and what does not belong to the message is masked afterwards.  A 16-byte
-// piece may reach up to 8 bytes past the conv state's words (np == 1, np == 3): into the neighbour's words or the rows that
-// follow the plane -- lazy mode keeps the back-pointer bytes behind every list, so the address is always inside the slot.
-// np == 0: nothing is kept (the empty message of the initial entries).
-template <int P> struct MsgRaw { lva_u32x4 lo; lva_u32x4 hi; };
-template <int P> __device__ __forceinline__ void load_msg_raw(const uint32_t* ent, uint32_t N, uint32_t c, uint32_t np, MsgRaw<P>* r) {
-  const uint32_t lo_off = np <= 1 ? 2 * c : 4 * c;
-  r->lo = *LVA_GLOBAL(lva_u32x4, ent + lo_off);
-  if constexpr (P >= 4) {
-    const uint32_t hi_off = np == 4 ? 4 * N + 4 * c : (np == 3 ? 4 * N + 2 * c : lo_off);
-    r->hi = *LVA_GLOBAL(lva_u32x4, ent + hi_off);
-  } else if constexpr (P == 3) {
-    const uint32_t hi_off = np == 3 ? 4 * N + 2 * c : lo_off;
-    const lva_u32x2 u = *LVA_GLOBAL(lva_u32x2, ent + hi_off);
-    r->hi.x = u.x; r->hi.y = u.y; r->hi.z = 0; r->hi.w = 0;
-  }
-}
-template <int P> __device__ __forceinline__ void msg_from_raw(const MsgRaw<P>& r, uint32_t np, uint32_t (&m)[2 * P]) {
-  m[0] = np >= 1 ? r.lo.x : 0u; m[1] = np >= 1 ? r.lo.y : 0u;
-  if constexpr (P >= 2) { m[2] = np >= 2 ? r.lo.z : 0u; m[3] = np >= 2 ? r.lo.w : 0u; }
-  if constexpr (P >= 3) { m[4] = np >= 3 ? r.hi.x : 0u; m[5] = np >= 3 ? r.hi.y : 0u; }
-  if constexpr (P >= 4) { m[6] = np >= 4 ? r.hi.z : 0u; m[7] = np >= 4 ? r.hi.w : 0u; }
 }
 // non-temporal stores: written once, next read by another CU a step later (+4 % measured)
 template <int P> __device__ __forceinline__ void store_msg(uint32_t* __restrict__ ent, uint32_t N, uint32_t c, uint32_t np,
@@ -894,12 +852,12 @@ __device__ __forceinline__ bool fast_output(const Geometry& g, const uint32_t* _
 // target must be redone by the exact path.
 // The merge proper: decides the new list (scores and fingerprints are stored as it goes) and reports where every accepted
 // entry came from (asrc) and which fingerprint matches still have to be verified on the full message (rej0 / rej1).
-template <int LL, int NL, bool PRE = false>
+template <int LL, int NL>
 __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur,
                                                 const uint2* s_src, const float* s_post, uint32_t k, uint32_t c,
                                                 uint32_t sc, uint32_t own, uint32_t okmask, uint32_t fpc,
                                                 unsigned long long* o_asrc, unsigned long long* o_rej0, unsigned long long* o_rej1,
-                                                uint32_t* o_lc, const uint2 (&pre)[LL]) {
+                                                uint32_t* o_lc) {
   const float NEG = -INFINITY;
   const uint32_t sBlk = g.sBlk;
   const uint32_t row = k >= 4 ? 4u : k;
@@ -907,15 +865,12 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
   int why = 0;
 
   // the target's own ("stay") list lives in registers, transition score already added
-  // (pre: the caller requested its (score, fingerprint) pairs earlier)
   float st_s[LL]; uint32_t st_h[LL];
   const float add0 = s_post[row * 8 + k];
   if (okmask & 1u) {
 #pragma unroll
     for (int l = 0; l < LL; ++l) {
-      uint2 v;
-      if constexpr (PRE) v = pre[l];
-      else v = *reinterpret_cast<const uint2*>(prev + own_c + l * sBlk);
+      const uint2 v = *reinterpret_cast<const uint2*>(prev + own_c + l * sBlk);
       const float raw = u2f(v.x);
       st_s[l] = raw != NEG ? raw + add0 : NEG;
       if (raw != NEG && !(st_s[l] > NEG)) why = 2;       // non-finite sum: the exact path decides
@@ -994,23 +949,8 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
     }
     // de-duplicate on fingerprints (:778-779): position q in ah <-> accepted entry lc-1-q
     int q = -1;
-#if LVA_DEDUP_ASM
-    if constexpr (LL == 8) {
-      // eight compares into eight SGPR pairs, then the selects: no select waits for the compare in front of it
-      // (the compiler's schedule reuses one pair and pays two wait states per entry)
-      unsigned long long c0, c1, c2, c3, c4, c5, c6, c7;
-      asm("v_cmp_ne_u32_e64 %1, %9, %17\n\tv_cmp_ne_u32_e64 %2, %10, %17\n\tv_cmp_ne_u32_e64 %3, %11, %17\n\tv_cmp_ne_u32_e64 %4, %12, %17\n\t"
-          "v_cmp_ne_u32_e64 %5, %13, %17\n\tv_cmp_ne_u32_e64 %6, %14, %17\n\tv_cmp_ne_u32_e64 %7, %15, %17\n\tv_cmp_ne_u32_e64 %8, %16, %17\n\t"
-          "v_cndmask_b32_e64 %0, 7, %0, %1\n\tv_cndmask_b32_e64 %0, 6, %0, %2\n\tv_cndmask_b32_e64 %0, 5, %0, %3\n\tv_cndmask_b32_e64 %0, 4, %0, %4\n\t"
-          "v_cndmask_b32_e64 %0, 3, %0, %5\n\tv_cndmask_b32_e64 %0, 2, %0, %6\n\tv_cndmask_b32_e64 %0, 1, %0, %7\n\tv_cndmask_b32_e64 %0, 0, %0, %8"
-          : "+v"(q), "=&s"(c7), "=&s"(c6), "=&s"(c5), "=&s"(c4), "=&s"(c3), "=&s"(c2), "=&s"(c1), "=&s"(c0)
-          : "v"(ah[7]), "v"(ah[6]), "v"(ah[5]), "v"(ah[4]), "v"(ah[3]), "v"(ah[2]), "v"(ah[1]), "v"(ah[0]), "v"(ch));
-    } else
-#endif
-    {
 #pragma unroll
-      for (int a = LL - 1; a >= 0; --a) q = ah[a] == ch ? a : q;
-    }
+    for (int a = LL - 1; a >= 0; --a) q = ah[a] == ch ? a : q;
     const bool isdup = q >= 0 && (uint32_t)q < lc;
     const bool accept = proceed && !isdup, reject = proceed && isdup;
     const uint32_t s7 = 7u * (lc - 1u - (uint32_t)q);          // (only meaningful when reject)
@@ -1057,8 +997,7 @@ __device__ __forceinline__ int fast_merge(const Geometry& g, const uint32_t* __r
                                            uint32_t nb, uint32_t fpc, uint32_t np_dst, uint32_t np_src) {
   unsigned long long asrc, rej0, rej1;
   uint32_t lc;
-  const uint2 none[LL] = {};
-  const int why = fast_merge_core<LL, NL>(g, prev, cur, s_src, s_post, k, c, sc, own, okmask, fpc, &asrc, &rej0, &rej1, &lc, none);
+  const int why = fast_merge_core<LL, NL>(g, prev, cur, s_src, s_post, k, c, sc, own, okmask, fpc, &asrc, &rej0, &rej1, &lc);
   if (why) return why;
   return fast_output<LL, P>(g, prev, cur, k, c, cp, own, src, sh, nb, np_dst, np_src, asrc, rej0, rej1, lc, 0, LL) ? 0 : 4;
 }
@@ -1314,21 +1253,6 @@ __device__ __forceinline__ void lazy_message(const LazyCtx& x, uint32_t i, uint3
 #endif
 }
 
-// The same in two halves without control flow in between: request the stored message's pieces (lazy_request), and once they
-// have arrived apply the moves (lazy_finish).  mv: planes in use | total shift << 4 | new bits << 8.
-template <int P>
-__device__ __forceinline__ void lazy_request(const LazyCtx& x, uint32_t i, uint32_t j, uint32_t bp1, MsgRaw<P>* raw, uint32_t* mv) {
-  const uint32_t* ent; uint32_t conv, np, s1, n1, s2;
-  if (!lazy_locate(x, i, j, bp1, &ent, &conv, &np, &s1, &n1, &s2)) np = 0;      // (t == 0, uniform: the empty message)
-  load_msg_raw<P>(ent, x.N, conv, np, raw);
-  *mv = np | ((s1 + s2) << 4) | (((n1 << s2) | (s2 ? x.nb_p : 0u)) << 8);
-}
-template <int P>
-__device__ __forceinline__ void lazy_finish(const MsgRaw<P>& raw, uint32_t mv, uint32_t (&m)[2 * P]) {
-  msg_from_raw<P>(raw, mv & 15u, m);
-  push_var<2 * P>(m, (mv >> 4) & 15u, mv >> 8);
-}
-
 __device__ __forceinline__ void lazy_ctx(const DevCode& cd, const Geometry& g, const SlotStep& ss, const uint32_t* slot_base, uint32_t pos,
                                          uint32_t c, uint32_t cp, uint32_t k, uint32_t own, LazyCtx* x) {
   x->M0 = slot_base; x->M1 = slot_base + g.sPar;
@@ -1377,41 +1301,6 @@ __device__ __forceinline__ bool lazy_output(const Geometry& g, const LazyCtx& x,
       }
     }
   };
-#if LVA_VERIFY_PASS
-  static_assert(LVA_REJ_SLOTS == 1, "the verification pass reads one record per entry");
-  // Fingerprint matches are confirmed in a pass of their own over the entries that have one (about one per target): both
-  // messages are requested together, without control flow around the loads.  Inside the entry loop every confirmation was two
-  // HBM round trips one after the other, in every one of the eight iterations (some lane of the wavefront always has one).
-  auto verify_pass = [&]() __attribute__((always_inline)) {
-    uint32_t todo = 0;
-#pragma unroll
-    for (int l = 0; l < LL; ++l) todo |= ((uint32_t)(rej0 >> (7 * l + 6)) & 1u) << l;
-    while (todo) {
-      const uint32_t l = (uint32_t)__builtin_ctz(todo);
-      todo &= todo - 1u;
-      const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu, rec = (uint32_t)(rej0 >> (7 * l)) & 0x3Fu;
-      const uint32_t i = (a8 >> 3) & 7u, j = a8 & 7u, ri = rec >> 3, rj = rec & 7u;
-      uint32_t bpa = 0, bpb = 0;
-      if constexpr (ANCHOR) {
-        const uint32_t sa = s_bp[(list_crf(x.k, i ? i : 1u) * TS + sc) * LL + j], sb = s_bp[(list_crf(x.k, ri ? ri : 1u) * TS + sc) * LL + rj];
-        bpa = i == 0 ? (uint32_t)(own_bp >> (8 * j)) & 0xFFu : sa;
-        bpb = ri == 0 ? (uint32_t)(own_bp >> (8 * rj)) & 0xFFu : sb;
-      }
-      MsgRaw<P> ra, rb; uint32_t mva, mvb;
-      lazy_request<P>(x, i, j, bpa, &ra, &mva);
-      lazy_request<P>(x, ri, rj, bpb, &rb, &mvb);
-      uint32_t ma[2 * P], mb[2 * P];
-      lazy_finish<P>(ra, mva, ma);
-      lazy_finish<P>(rb, mvb, mb);
-#pragma unroll
-      for (int w = 0; w < 2 * P; ++w) good &= (ma[w] == mb[w]);
-    }
-  };
-  constexpr bool kVerifyInline = false;
-#else
-  auto verify_pass = [&]() __attribute__((always_inline)) {};
-  constexpr bool kVerifyInline = true;
-#endif
   if constexpr (!ANCHOR) {
     // ---- odd step: one byte per accepted entry; messages are touched only to confirm fingerprint matches ----
     unsigned long long packed = 0;
@@ -1420,52 +1309,19 @@ __device__ __forceinline__ bool lazy_output(const Geometry& g, const LazyCtx& x,
       if ((uint32_t)l < lc) {
         const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu;
         packed |= (unsigned long long)(a8 | (lazy_mbuf(x, a8 >> 3) << 6)) << (8 * l);
-        if (kVerifyInline && ((uint32_t)(rej0 >> (7 * l)) & 0x40u)) {
+        if ((uint32_t)(rej0 >> (7 * l)) & 0x40u) {
           uint32_t mw[2 * P];
           lazy_message<P>(x, a8 >> 3, a8 & 7u, 0u, mw);
           verify(l, mw);
         }
       }
     }
-    verify_pass();
     uint8_t* dst = reinterpret_cast<uint8_t*>(cur) + bp_byte_index(g, x.own, 0, x.c);
     if constexpr (LL == 8) *reinterpret_cast<unsigned long long*>(dst) = packed;
     else if constexpr (LL == 4) *reinterpret_cast<uint32_t*>(dst) = (uint32_t)packed;
     else *reinterpret_cast<uint16_t*>(dst) = (uint16_t)packed;
     return good;
   }
-#if LVA_ANCHOR_NOBRANCH
-  {
-    // ---- anchor step, no control flow around the loads: every lane requests the message pieces of GBN entries (entries it does
-    //      not have: its own entry 0, discarded), then shifts, stores and verifies.  The branchy version below waits for each
-    //      entry's pieces inside the branch that requested them -- one HBM round trip after the other.
-    constexpr int GBN = P >= 4 ? 2 : LVA_ANCHOR_GBN;
-#pragma unroll
-    for (int l0 = 0; l0 < LL; l0 += GBN) {
-      MsgRaw<P> raw[GBN]; uint32_t mv[GBN];
-#pragma unroll
-      for (int u = 0; u < GBN; ++u) {
-        const int l = l0 + u;
-        const uint32_t a8 = (uint32_t)l < lc ? (uint32_t)(asrc >> (8 * l)) & 0xFFu : 0u;
-        const uint32_t i = a8 >> 3, j = a8 & 7u;
-        const uint32_t bps = s_bp[(list_crf(x.k, i ? i : 1u) * TS + sc) * LL + j];          // (read whatever i is: no branch)
-        lazy_request<P>(x, i, j, i == 0 ? (uint32_t)(own_bp >> (8 * j)) & 0xFFu : bps, &raw[u], &mv[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < GBN; ++u) {
-        const int l = l0 + u;
-        uint32_t m[2 * P];
-        lazy_finish<P>(raw[u], mv[u], m);
-        if ((uint32_t)l < lc) {
-          store_msg<P>(mout + x.own + l * x.sBlk + x.pw, x.N, x.c, x.np_p, m);
-          if (kVerifyInline && ((uint32_t)(rej0 >> (7 * l)) & 0x40u)) verify(l, m);
-        }
-      }
-    }
-    verify_pass();
-    return good;
-  }
-#endif
   // ---- anchor step: two hops to the stored message, both moves applied, stored coalesced; LVA_LAZY_GB entries in flight ----
   // (four message planes: one entry in flight -- 8 more message registers would cost the anchor instance a wavefront per SIMD;
   //  measured at m=14: 4.91 against 4.69 reads/s)
@@ -1499,11 +1355,10 @@ __device__ __forceinline__ bool lazy_output(const Geometry& g, const LazyCtx& x,
         push_bits<2 * P>(m[u], mv[u] >> 4, x.nb_p);
 #endif
         store_msg<P>(mout + x.own + l * x.sBlk + x.pw, x.N, x.c, x.np_p, m[u]);
-        if (kVerifyInline && ((uint32_t)(rej0 >> (7 * l)) & 0x40u)) verify(l, m[u]);
+        if ((uint32_t)(rej0 >> (7 * l)) & 0x40u) verify(l, m[u]);
       }
     }
   }
-  verify_pass();
   return good;
 }
 
@@ -1550,18 +1405,6 @@ __global__ __launch_bounds__(8 * TS, ANCHOR ? LVA_LAZY_ANCHOR_MINWAVES : LVA_LAZ
     return;
   }
 
-#if LVA_LAZY_HOIST
-  // this thread's target and its stay list first: the loads travel with the staging loads instead of behind the barrier
-  TileTarget t;
-  const bool has_target = tile_target<TS>(cd, g, ss, pos, tile, tid, &t);
-  uint2 stv[LL];
-#pragma unroll
-  for (int l = 0; l < LL; ++l) stv[l] = make_uint2(kNegInfBits, 0u);
-  if (has_target && (t.ok & 1u)) {
-#pragma unroll
-    for (int l = 0; l < LL; ++l) stv[l] = *reinterpret_cast<const uint2*>(prev + t.own + 2 * t.c + l * g.sBlk);
-  }
-#endif
   // ---- stage the (score, fingerprint) pairs of 64 source conv states (and, for an anchor step, their back-pointer bytes) ----
   const uint32_t src = (uint32_t)((uint64_t)((pos - 1) % g.R) * 8 * g.sCrf);
   for (uint32_t chunk = tid; chunk < 8u * LL * (TS / 2); chunk += 8u * TS) {
@@ -1581,15 +1424,8 @@ __global__ __launch_bounds__(8 * TS, ANCHOR ? LVA_LAZY_ANCHOR_MINWAVES : LVA_LAZ
   if (tid < 40) s_post[tid] = LVA_GLOBAL(float, ss.post_row)[tid];
   __syncthreads();
 
-#if LVA_LAZY_HOIST
-  if (!has_target) return;
-  constexpr bool kPre = true;
-#else
   TileTarget t;
   if (!tile_target<TS>(cd, g, ss, pos, tile, tid, &t)) return;
-  constexpr bool kPre = false;
-  const uint2 stv[LL] = {};
-#endif
   // an anchor step needs the back-pointer bytes of its own (stay) list: requested now, used after the merge
   unsigned long long own_bp = 0;
   if (anchor && ss.t != 0 && (t.ok & 1u)) {
@@ -1600,8 +1436,8 @@ __global__ __launch_bounds__(8 * TS, ANCHOR ? LVA_LAZY_ANCHOR_MINWAVES : LVA_LAZ
   }
   unsigned long long asrc = 0, rej0 = 0, rej1 = 0;
   uint32_t lc = 0;
-  int why = t.k < 4 ? fast_merge_core<LL, 8, kPre>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &rej1, &lc, stv)
-                    : fast_merge_core<LL, 2, kPre>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &rej1, &lc, stv);
+  int why = t.k < 4 ? fast_merge_core<LL, 8>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &rej1, &lc)
+                    : fast_merge_core<LL, 2>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &rej1, &lc);
   if (!why) {
     LazyCtx x;
     lazy_ctx(cd, g, ss, slot_base, pos, t.c, t.cp, t.k, t.own, &x);
@@ -1823,63 +1659,6 @@ __global__ __launch_bounds__(4 * TS) void lva_step_acs(StepArgs args, Geometry g
     fast_acs<P, 2>(g, prev, cur, s_src, s_post, t.k, t.c, t.cp, t.sc, t.own, src, t.ok, t.sh, t.nb, t.fpc, t.np_dst, t.np_src);
 }
 
-// L == 1 on SMALL trellises (m <= 8): one workgroup takes PPW consecutive band positions of its tile.  A workgroup of
-// lva_step_acs moves ~15 KB behind a chain of dependent round trips (slot record -> staging -> barrier -> tables -> stay
-// entry / message -> store); with PPW positions the staging loads of all of them are in flight together and the chain is
-// paid once per PPW times the work.  Positions of one step are independent (all read the previous buffer).
-template <int P, int PPW>
-__global__ __launch_bounds__(4 * TS) void lva_step_acs_multi(StepArgs args, Geometry g, const DevCode* __restrict__ codes,
-                                                             uint32_t* __restrict__ trellis) {
-  __shared__ uint2 s_src[PPW][8 * TS];
-  __shared__ float s_post[40];
-  SlotStep ss;
-  if (!load_slot(args, blockIdx.z, &ss)) return;
-  const uint32_t pos0 = ss.lo + blockIdx.y * PPW;
-  if (pos0 >= ss.hi) return;
-  const DevCode& cd = codes[ss.orient];
-  const uint32_t N = cd.nconv, tid = threadIdx.x, tile = blockIdx.x;
-  const uint32_t* prev; uint32_t* cur;
-  slot_buffers(ss, g, trellis, &prev, &cur);
-  uint4 v[PPW];
-  const uint32_t rowi = tid / (TS / 2), lane2 = tid % (TS / 2);
-#pragma unroll
-  for (int pp = 0; pp < PPW; ++pp) {
-    const uint32_t pos = pos0 + pp;
-    v[pp] = make_uint4(kNegInfBits, 0u, kNegInfBits, 0u);
-    if (pos < ss.hi && pos != 0) {
-      const uint32_t src = (uint32_t)((uint64_t)((pos - 1) % g.R) * 8 * g.sCrf);
-      v[pp] = *reinterpret_cast<const uint4*>(prev + src + (uint64_t)rowi * g.sBlk + 2 * (tile * TS) + 4 * lane2);
-    }
-  }
-#pragma unroll
-  for (int pp = 0; pp < PPW; ++pp) *reinterpret_cast<uint4*>(&s_src[pp][rowi * TS + 2 * lane2]) = v[pp];
-  if (tid < 40) s_post[tid] = LVA_GLOBAL(float, ss.post_row)[tid];
-  __syncthreads();
-#pragma unroll
-  for (int pp = 0; pp < PPW; ++pp) {
-    const uint32_t pos = pos0 + pp;
-    if (pos >= ss.hi) break;
-    if (pos == 0) {                        // stay-only update of the 8 start states (:706-713)
-      if (tile == cd.init / TS && tid < 8) {
-        const uint32_t k = tid, c = cd.init;
-        const uint32_t own_c = (uint32_t)((uint64_t)k * g.sCrf) + 2 * c;
-        const float sc0 = u2f(prev[own_c]) + s_post[(k >= 4 ? 4u : k) * 8 + k];
-        cur[own_c] = f2u(sc0);
-        cur[own_c + 1] = prev[own_c + 1];
-        cur[own_c + 2 * N] = prev[own_c + 2 * N];
-        cur[own_c + 2 * N + 1] = prev[own_c + 2 * N + 1];
-      }
-      continue;
-    }
-    const uint32_t src = (uint32_t)((uint64_t)((pos - 1) % g.R) * 8 * g.sCrf);
-    TileTarget t;
-    if (tile_target<TS>(cd, g, ss, pos, tile, tid, &t))
-      fast_acs<P, 8>(g, prev, cur, s_src[pp], s_post, t.k, t.c, t.cp, t.sc, t.own, src, t.ok, t.sh, t.nb, t.fpc, t.np_dst, t.np_src);
-    if (tile_target<TS>(cd, g, ss, pos, tile, tid + 4 * TS, &t))
-      fast_acs<P, 2>(g, prev, cur, s_src[pp], s_post, t.k, t.c, t.cp, t.sc, t.own, src, t.ok, t.sh, t.nb, t.fpc, t.np_dst, t.np_src);
-  }
-}
-
 // ---------------------------------------------------------------------------------------
 // big-list fast kernel: list sizes 2 <= L <= 64 that lva_step_fast has no instance for
 // (LL = 16, 32 or 64 >= L is the compile-time capacity).  Same butterfly tiling and the same
@@ -2020,70 +1799,6 @@ __device__ __forceinline__ int big_merge(const Geometry& g, const uint32_t* __re
     *i_out = i;
     return (i == 0 ? t.own : src + mul24(list_crf(k, i), sCrf)) + mul24(j, sBlk);
   };
-#if LVA_BIG_NOBRANCH
-  // outputs, entry l of the whole wavefront at a time (:771-774, :780-783, :799), WITHOUT control flow around the loads: every
-  // lane requests (score, fingerprint) and both message pieces of GB entries -- for entries it does not have, of its own
-  // entry 0, discarded -- and only then shifts and stores.  (With the loads inside `if (l < lc)` / `if (np == ...)` the
-  // compiler waits for each piece in the branch that requested it: 64 entries, one HBM round trip after the other.)
-  bool good = true;
-  constexpr uint32_t GB = LL >= 64 ? LVA_BIG_GB : 4;
-  for (uint32_t l0 = 0; l0 < L; l0 += GB) {
-    MsgRaw<P> raw[GB]; lva_u32x2 sh2[GB]; uint32_t iu[GB];
-#pragma unroll
-    for (uint32_t u = 0; u < GB; ++u) {
-      const uint32_t l = l0 + u, lx = l < (uint32_t)LL ? l : (uint32_t)LL - 1u;
-      const uint32_t raw9 = (uint32_t)s_acc[lx * NT] | ((uint32_t)(acc_hi >> lx) & 1u) << 8;
-      const uint32_t from9 = l < lc ? raw9 : 0u;
-      const uint32_t f = locate(from9, &iu[u]);
-      const uint32_t cv = iu[u] == 0 ? t.c : t.cp;
-      sh2[u] = *LVA_GLOBAL(lva_u32x2, prev + f + 2 * cv);
-      load_msg_raw<P>(prev + f + pw, N, cv, iu[u] == 0 ? t.np_dst : t.np_src, &raw[u]);
-    }
-#pragma unroll
-    for (uint32_t u = 0; u < GB; ++u) {
-      const uint32_t l = l0 + u;
-      uint32_t m[2 * P];
-      msg_from_raw<P>(raw[u], iu[u] == 0 ? t.np_dst : t.np_src, m);
-      push_var<2 * P>(m, iu[u] == 0 ? 0u : t.sh, iu[u] == 0 ? 0u : t.nb);
-      if (l < lc) {
-        const float sc = u2f(sh2[u].x) + ladd(iu[u]);
-        *reinterpret_cast<uint2*>(cur + own_c + mul24(l, sBlk)) = make_uint2(f2u(sc), iu[u] ? sh2[u].y ^ t.fpc : sh2[u].y);
-        store_msg<P>(cur + t.own + mul24(l, sBlk) + pw, N, t.c, t.np_dst, m);
-      } else if (l < L) {
-        *reinterpret_cast<uint2*>(cur + own_c + mul24(l, sBlk)) = make_uint2(kNegInfBits, 0u);
-      }
-    }
-  }
-  // every fingerprint match filed under an entry must be the same message (else: a collision, the exact path decides).
-  // One in ten entries has one: a pass of its own over the set bits, both messages fetched again.
-  unsigned long long todo = rv0;
-  while (todo) {
-    const uint32_t l = (uint32_t)__builtin_ctzll(todo);
-    todo &= todo - 1ull;
-    uint32_t ia, ib;
-    const uint32_t fa = locate((uint32_t)s_acc[l * NT] | ((uint32_t)(acc_hi >> l) & 1u) << 8, &ia);
-    const uint32_t fb = locate((uint32_t)s_rej0[l * NT] | ((uint32_t)(rh0 >> l) & 1u) << 8, &ib);
-    MsgRaw<P> ra, rb;
-    load_msg_raw<P>(prev + fa + pw, N, ia == 0 ? t.c : t.cp, ia == 0 ? t.np_dst : t.np_src, &ra);
-    load_msg_raw<P>(prev + fb + pw, N, ib == 0 ? t.c : t.cp, ib == 0 ? t.np_dst : t.np_src, &rb);
-    uint32_t ma[2 * P], mb[2 * P];
-    msg_from_raw<P>(ra, ia == 0 ? t.np_dst : t.np_src, ma);
-    msg_from_raw<P>(rb, ib == 0 ? t.np_dst : t.np_src, mb);
-    push_var<2 * P>(ma, ia == 0 ? 0u : t.sh, ia == 0 ? 0u : t.nb);
-    push_var<2 * P>(mb, ib == 0 ? 0u : t.sh, ib == 0 ? 0u : t.nb);
-#pragma unroll
-    for (int w = 0; w < 2 * P; ++w) good &= (ma[w] == mb[w]);
-    if ((rv1 >> l) & 1ull) {               // a second match on the same entry: rare
-      uint32_t i1;
-      const uint32_t fr = locate((uint32_t)s_rej1[l * NT] | ((uint32_t)(rh1 >> l) & 1u) << 8, &i1);
-      uint32_t qm[2 * P];
-      load_msg<P>(prev + fr + pw, N, i1 == 0 ? t.c : t.cp, i1 == 0 ? t.np_dst : t.np_src, qm);
-      push_bits<2 * P>(qm, i1 == 0 ? 0u : t.sh, t.nb);
-#pragma unroll
-      for (int w = 0; w < 2 * P; ++w) good &= (qm[w] == ma[w]);
-    }
-  }
-#else
   // outputs, entry l of the whole wavefront at a time (:771-774, :780-783, :799).  Every fingerprint
   // match filed under an entry must be the same message (else: collision, the exact path decides).
   bool good = true;
@@ -2140,7 +1855,6 @@ __device__ __forceinline__ int big_merge(const Geometry& g, const uint32_t* __re
       }
     }
   }
-#endif
   return good ? 0 : 4;
 }
 
@@ -2399,19 +2113,6 @@ int launch_step_fast(const StepArgs& a, const Geometry& g, const DevCode* codes,
   switch (g.L) {
 #if LVA_ACS_KERNEL
     case 1: {
-      constexpr int kPPW = LVA_ACS_PPW;
-      if (kPPW > 1 && g.N <= 256) {        // small trellises: PPW band positions per workgroup
-        dim3 grid(g.N / TS, (a.band_max + kPPW - 1) / kPPW, a.nslots), block(4 * TS);
-        switch (g.P) {
-          case 1: hipLaunchKernelGGL((lva_step_acs_multi<1, kPPW>), grid, block, 0, st, a, g, codes, trellis); break;
-          case 2: hipLaunchKernelGGL((lva_step_acs_multi<2, kPPW>), grid, block, 0, st, a, g, codes, trellis); break;
-          case 3: hipLaunchKernelGGL((lva_step_acs_multi<3, kPPW>), grid, block, 0, st, a, g, codes, trellis); break;
-          case 4: hipLaunchKernelGGL((lva_step_acs_multi<4, kPPW>), grid, block, 0, st, a, g, codes, trellis); break;
-          default: return (int)hipErrorInvalidValue;
-        }
-        e = (int)hipGetLastError();
-        break;
-      }
       dim3 grid(g.N / TS, a.band_max, a.nslots), block(4 * TS);
       switch (g.P) {
         case 1: hipLaunchKernelGGL((lva_step_acs<1>), grid, block, 0, st, a, g, codes, trellis); break;
