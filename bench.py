@@ -243,9 +243,9 @@ def main():
                  3: "lva_step_wave", 1: "lva_step_exact"}.get(prof["kernel"], "?")
         # HBM bytes per launch from this round's PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
         # passes, scripts/pmc_mem.sh), per read-step, scaled to this run's mean number of active slots per launch
-        traffic, tsrc = None, None
+        traffic, tsrc, limiter = None, None, None
         try:
-            for name in ("r2_traffic.json", "r1_traffic.json"):
+            for name in ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
                 pth = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(pth):
                     tj = json.load(open(pth))
@@ -254,12 +254,16 @@ def main():
                         per_rs = (tj["fetch_correction"] * tj["fetch_size_kb_per_launch"] + tj["write_size_kb_per_launch"]) * 1024.0 / tj["slots"]
                         traffic = per_rs * (acc["read_steps"] / acc["launches"])
                         tsrc = "profiles/" + name + " (PMC run of an earlier invocation, scaled per read-step)"
+                        limiter = tj.get("limiter")
                     break
         except Exception:
             traffic = None
         res["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
             "traffic": traffic, "traffic_source": tsrc,
+            # what the counters say holds the kernel back (the HBM roofline above stays the yardstick of the contract):
+            # from the committed PMC profile of the same kernels, not measured in this run
+            "limiter": limiter,
             "kernel": kname + " (one trellis step of every active read slot)",
             "basis": ("algorithmic bytes / sum of per-launch HIP-event times of the dominant kernel alone" if use_events
                       else "algorithmic bytes / HIP-event span first..last step launch"),
