@@ -693,6 +693,13 @@ namespace {
 #ifndef LVA_FIXUP_LAZY_GRID
 #define LVA_FIXUP_LAZY_GRID 4096   // workgroups (of four wavefronts) of lva_step_fixup_lazy
 #endif
+#ifndef LVA_VERIFY_LOOP
+#define LVA_VERIFY_LOOP 1      // fingerprint matches confirmed in a loop over the entries that have one: 1 odd instance (+0.7 %), 2 both (-3 %)
+#endif
+#ifndef LVA_ABLATE
+#define LVA_ABLATE 0           // timing-only builds of the lazy pair.  Results stay correct: 6 = the merge once more without its
+#endif                         // stores, 7 = the output phase once more.  Results WRONG: 2 = merge loop capped at 8 iterations, 3 = no
+                               // confirmation of fingerprint matches, 5 = no merge and no output at all
 #ifndef LVA_LAZY_GB
 #define LVA_LAZY_GB 2
 #endif
@@ -852,7 +859,7 @@ __device__ __forceinline__ bool fast_output(const Geometry& g, const uint32_t* _
 // target must be redone by the exact path.
 // The merge proper: decides the new list (scores and fingerprints are stored as it goes) and reports where every accepted
 // entry came from (asrc) and which fingerprint matches still have to be verified on the full message (rej0 / rej1).
-template <int LL, int NL>
+template <int LL, int NL, bool DRY = false>
 __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur,
                                                 const uint2* s_src, const float* s_post, uint32_t k, uint32_t c,
                                                 uint32_t sc, uint32_t own, uint32_t okmask, uint32_t fpc,
@@ -907,6 +914,9 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
   // The loop body is written branch-free (selects) except for the store of an accepted entry:
   // lanes that are done keep running harmless iterations until the wavefront's last lane exits.
   bool go = why == 0;
+#if LVA_ABLATE == 2
+  int abl_it = 0;
+#endif
   while (go) {                                                         // :764
     float M = h[0];
 #pragma unroll
@@ -966,7 +976,7 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
     rej0 |= (reject && !full0) ? rec << (s7 & 63u) : 0ull;
     if constexpr (kSecond) rej1 |= (full0 && !full1) ? rec << (s7 & 63u) : 0ull;
     if (accept) {
-      *reinterpret_cast<uint2*>(cur + own_c + mul24(lc, sBlk)) = make_uint2(f2u(M), ch);   // :780-783
+      if constexpr (!DRY) *reinterpret_cast<uint2*>(cur + own_c + mul24(lc, sBlk)) = make_uint2(f2u(M), ch);   // :780-783
 #pragma unroll
       for (int a = LL - 1; a >= 1; --a) ah[a] = opq(ah[a - 1]);
       ah[0] = ch;
@@ -979,13 +989,18 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
     ptr += 1u << (4 * sel);
     why = (alive && two) ? 1 : ((proceed && bad) ? 2 : ((full0 && full1) ? 3 : 0));
     go = proceed && why == 0 && lc < (uint32_t)LL;
+#if LVA_ABLATE == 2
+    if (++abl_it >= 8) go = false;
+#endif
   }
   if (why) return why;
 
   // unused tail of the list (:799)
+  if constexpr (!DRY) {
 #pragma unroll
-  for (int l = 0; l < LL; ++l)
-    if ((uint32_t)l >= lc) *reinterpret_cast<uint2*>(cur + own_c + l * sBlk) = make_uint2(kNegInfBits, 0u);
+    for (int l = 0; l < LL; ++l)
+      if ((uint32_t)l >= lc) *reinterpret_cast<uint2*>(cur + own_c + l * sBlk) = make_uint2(kNegInfBits, 0u);
+  }
   *o_asrc = asrc; *o_rej0 = rej0; *o_rej1 = rej1; *o_lc = lc;
   return 0;
 }
@@ -1289,6 +1304,9 @@ __device__ __forceinline__ bool lazy_output(const Geometry& g, const LazyCtx& x,
   };
   // every fingerprint match filed under entry l must be the same message as the entry's (mw)
   auto verify = [&](int l, const uint32_t (&mw)[2 * P]) __attribute__((always_inline)) {
+#if LVA_ABLATE == 3
+    return;
+#endif
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       const uint32_t rec = (uint32_t)((s2 ? rej1 : rej0) >> (7 * l)) & 0x7Fu;
@@ -1301,6 +1319,26 @@ __device__ __forceinline__ bool lazy_output(const Geometry& g, const LazyCtx& x,
       }
     }
   };
+  // Confirmation of the fingerprint matches as a loop over the entries that HAVE one (about one per target, rarely more than
+  // three): inside the unrolled entry loop each of the eight `if (match filed under entry l)` blocks runs for the whole
+  // wavefront as soon as one lane has a match there -- always -- so a wavefront executed eight confirmations for one per lane.
+  constexpr bool kVerifyLoop = LVA_VERIFY_LOOP == 2 || (LVA_VERIFY_LOOP == 1 && !ANCHOR);
+  auto verify_loop = [&]() __attribute__((always_inline)) {
+    static_assert(!kVerifyLoop || LVA_REJ_SLOTS == 1, "one record per entry");
+    uint32_t todo = 0;
+#pragma unroll
+    for (int l = 0; l < LL; ++l) todo |= ((uint32_t)(rej0 >> (7 * l + 6)) & 1u) << l;
+    while (todo) {
+      const uint32_t l = (uint32_t)__builtin_ctz(todo);
+      todo &= todo - 1u;
+      const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0x3Fu, rec = (uint32_t)(rej0 >> (7 * l)) & 0x3Fu;
+      uint32_t ma[2 * P], mb[2 * P];
+      lazy_message<P>(x, a8 >> 3, a8 & 7u, ANCHOR ? bp_of(a8 >> 3, a8 & 7u) : 0u, ma);
+      lazy_message<P>(x, rec >> 3, rec & 7u, ANCHOR ? bp_of(rec >> 3, rec & 7u) : 0u, mb);
+#pragma unroll
+      for (int w = 0; w < 2 * P; ++w) good &= (ma[w] == mb[w]);
+    }
+  };
   if constexpr (!ANCHOR) {
     // ---- odd step: one byte per accepted entry; messages are touched only to confirm fingerprint matches ----
     unsigned long long packed = 0;
@@ -1309,7 +1347,7 @@ __device__ __forceinline__ bool lazy_output(const Geometry& g, const LazyCtx& x,
       if ((uint32_t)l < lc) {
         const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu;
         packed |= (unsigned long long)(a8 | (lazy_mbuf(x, a8 >> 3) << 6)) << (8 * l);
-        if ((uint32_t)(rej0 >> (7 * l)) & 0x40u) {
+        if (!kVerifyLoop && ((uint32_t)(rej0 >> (7 * l)) & 0x40u)) {
           uint32_t mw[2 * P];
           lazy_message<P>(x, a8 >> 3, a8 & 7u, 0u, mw);
           verify(l, mw);
@@ -1320,6 +1358,7 @@ __device__ __forceinline__ bool lazy_output(const Geometry& g, const LazyCtx& x,
     if constexpr (LL == 8) *reinterpret_cast<unsigned long long*>(dst) = packed;
     else if constexpr (LL == 4) *reinterpret_cast<uint32_t*>(dst) = (uint32_t)packed;
     else *reinterpret_cast<uint16_t*>(dst) = (uint16_t)packed;
+    if constexpr (kVerifyLoop) verify_loop();
     return good;
   }
   // ---- anchor step: two hops to the stored message, both moves applied, stored coalesced; LVA_LAZY_GB entries in flight ----
@@ -1355,10 +1394,11 @@ __device__ __forceinline__ bool lazy_output(const Geometry& g, const LazyCtx& x,
         push_bits<2 * P>(m[u], mv[u] >> 4, x.nb_p);
 #endif
         store_msg<P>(mout + x.own + l * x.sBlk + x.pw, x.N, x.c, x.np_p, m[u]);
-        if ((uint32_t)(rej0 >> (7 * l)) & 0x40u) verify(l, m[u]);
+        if (!kVerifyLoop && ((uint32_t)(rej0 >> (7 * l)) & 0x40u)) verify(l, m[u]);
       }
     }
   }
+  if constexpr (kVerifyLoop) verify_loop();
   return good;
 }
 
@@ -1436,12 +1476,27 @@ __global__ __launch_bounds__(8 * TS, ANCHOR ? LVA_LAZY_ANCHOR_MINWAVES : LVA_LAZ
   }
   unsigned long long asrc = 0, rej0 = 0, rej1 = 0;
   uint32_t lc = 0;
+#if LVA_ABLATE == 5
+  if (tid < 4096) return;
+#endif
+#if LVA_ABLATE == 6       // the merge once more without its stores, result kept alive through an impossible condition
+  {
+    unsigned long long a2 = 0, r2 = 0, r3 = 0; uint32_t lc2 = 0;
+    const int w2 = t.k < 4 ? fast_merge_core<LL, 8, true>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &a2, &r2, &r3, &lc2)
+                           : fast_merge_core<LL, 2, true>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &a2, &r2, &r3, &lc2);
+    if (w2 == 77 || lc2 + (uint32_t)a2 + (uint32_t)r2 == 0xFEEDBEEFu) hdr->pad = 1u;
+  }
+#endif
   int why = t.k < 4 ? fast_merge_core<LL, 8>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &rej1, &lc)
                     : fast_merge_core<LL, 2>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &rej1, &lc);
   if (!why) {
     LazyCtx x;
     lazy_ctx(cd, g, ss, slot_base, pos, t.c, t.cp, t.k, t.own, &x);
     if (!lazy_output<LL, P, ANCHOR>(g, x, cur, mout, s_bp, t.sc, own_bp, asrc, rej0, rej1, lc)) why = 4;
+#if LVA_ABLATE == 7       // the output phase once more (the same stores again: idempotent)
+    asm volatile("" ::: "memory");
+    if (!lazy_output<LL, P, ANCHOR>(g, x, cur, mout, s_bp, t.sc, own_bp, asrc, rej0, rej1, lc)) why = 4;
+#endif
   }
   if (why) {
     atomicAdd(&hdr->reason[why - 1], 1ull);
