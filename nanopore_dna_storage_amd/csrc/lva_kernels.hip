@@ -1739,9 +1739,6 @@ namespace {
 #ifndef LVA_BIG_SHSTORE
 #define LVA_BIG_SHSTORE 0      // 1: accepted (score, fingerprint) pairs stored inside the merge loop: 6.94 instead of 6.14 ms per launch
 #endif
-#ifndef LVA_BIG_ONE_REJ
-#define LVA_BIG_ONE_REJ 0
-#endif
 #ifndef LVA_BIG_GB
 #define LVA_BIG_GB 6
 #endif
@@ -1828,14 +1825,9 @@ __device__ __forceinline__ int big_merge(const Geometry& g, const uint32_t* __re
     acc_hi |= accept ? hi9 << lc : 0ull;
     const uint32_t ra = lc - 1u - (uint32_t)q;                 // the entry it matched (only meaningful when reject)
     const unsigned long long rbit = 1ull << (ra & 63u);
-#if LVA_BIG_ONE_REJ       // one match per accepted entry (as the 8-entry kernels): a second one goes to the exact path; a third of the LDS saved
-    const bool use0 = reject && !(rv0 & rbit), use1 = false, rej_full = reject && !use0;
-    if (use0) s_rej0[ra * NT] = (uint8_t)from9;
-#else
     const bool use0 = reject && !(rv0 & rbit), use1 = reject && !use0 && !(rv1 & rbit), rej_full = reject && !use0 && !use1;
     if (use0) s_rej0[ra * NT] = (uint8_t)from9;
     if (use1) s_rej1[ra * NT] = (uint8_t)from9;
-#endif
     rv0 |= use0 ? rbit : 0ull; rh0 |= (use0 && hi9) ? rbit : 0ull;
     rv1 |= use1 ? rbit : 0ull; rh1 |= (use1 && hi9) ? rbit : 0ull;
 #pragma unroll
@@ -1928,12 +1920,7 @@ template <int LL, int P>
 __global__ __launch_bounds__(8 * TSB) void lva_step_big(StepArgs args, Geometry g, const DevCode* __restrict__ codes,
                                                       uint32_t* __restrict__ trellis, WorkHdr* __restrict__ hdr,
                                                       uint32_t* __restrict__ items) {
-#if LVA_BIG_ONE_REJ
-  __shared__ uint8_t s_acc[LL * 8 * TSB], s_rej0[LL * 8 * TSB];
-  uint8_t* s_rej1 = s_rej0;
-#else
   __shared__ uint8_t s_acc[LL * 8 * TSB], s_rej0[LL * 8 * TSB], s_rej1[LL * 8 * TSB];
-#endif
   __shared__ float s_post[40];
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
     hdr->count[args.step_parity ^ 1u] = 0;     // the other parity's list was consumed by the last fix-up
