@@ -197,3 +197,40 @@ def test_crc_index_filter_against_reference_vectors():
     assert 10 < hits < len(g["filter"])
     for x in g["parameters"]:
         assert list(helper.compute_parameters(x["bytes_per_oligo"], x["RS_redundancy"], x["data_size_padded"], x["pad"])) == x["result"]
+
+
+def test_error_rate_script_on_list_files(tmp_path):
+    """compute_error_rate_from_decoded_lists.py:18-56 over list_<i> files: correct / erased / wrong-CRC-match tallies (host only)"""
+    import io
+    from nanopore_dna_storage_amd import compute_error_rate_from_decoded_lists as cer
+    payloads = [bytes([i] * 4) for i in range(3)]
+    conv_in = [helper.attach_index_crc(i, p) for i, p in enumerate(payloads)]
+    (tmp_path / "conv_input.txt").write_text("\n".join(conv_in) + "\n")
+    d = tmp_path / "lists"
+    d.mkdir()
+    junk = "0" * len(conv_in[0])
+    (d / "list_0").write_text(junk + "\n" + conv_in[0] + "\n")                 # second entry passes: correct
+    (d / "list_1").write_text(junk + "\n")                                     # nothing passes: erasure
+    (d / "list_2").write_text(helper.attach_index_crc(1, bytes([9] * 4)) + "\n")   # valid CRC and index, wrong payload: error
+    (d / "other.txt").write_text("ignored\n")
+    out = io.StringIO()
+    t = cer.main(["--list_size", "8", "--decoded_lists_dir", str(d), "--conv_input_file", str(tmp_path / "conv_input.txt"),
+                  "--bytes_per_oligo", "4"], out=out)
+    assert t == dict(num_reads=3, num_correct=1, num_erasure_CRC_index=1, num_error_CRC_index=1)
+    assert "num_oligos 3" in out.getvalue() and "num_error_CRC_index: 1" in out.getvalue()
+    # list_size 1: the correct entry of list_0 is out of reach
+    t1 = cer.main(["--list_size", "1", "--decoded_lists_dir", str(d), "--conv_input_file", str(tmp_path / "conv_input.txt"),
+                   "--bytes_per_oligo", "4"], out=io.StringIO())
+    assert t1["num_correct"] == 0 and t1["num_erasure_CRC_index"] == 2
+
+
+def test_list_files_are_written_atomically(tmp_path):
+    """generate_decoded_lists writes OUT_PREFIX_i under a temporary name and renames it: no partial file can pass for a finished read"""
+    from nanopore_dna_storage_amd import generate_decoded_lists as gdl
+    p = tmp_path / "list_7"
+    gdl.write_list_file(str(p), np.array([[1, 0, 1], [0, 0, 1]], np.uint8))
+    assert p.read_text() == "101\n001\n"
+    assert [f.name for f in tmp_path.iterdir()] == ["list_7"]
+    args = gdl.build_parser().parse_args(["--post_manifest", "m", "--out_prefix", "o", "--info_file", "i", "--mem_conv", "6", "--msg_len", "60",
+                                          "--rate_conv", "1", "--list_size", "4"])
+    assert args.chunk == 4096 and args.max_deviation == 20 and args.gpus == 1
