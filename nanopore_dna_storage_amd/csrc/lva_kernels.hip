@@ -693,6 +693,9 @@ namespace {
 #ifndef LVA_FIXUP_LAZY_GRID
 #define LVA_FIXUP_LAZY_GRID 4096   // workgroups (of four wavefronts) of lva_step_fixup_lazy
 #endif
+#ifndef LVA_VERIFY_PAIRED
+#define LVA_VERIFY_PAIRED 1      // odd instance: both messages of a confirmation requested together behind uniform branches (+1.2 %)
+#endif
 #ifndef LVA_VERIFY_LOOP
 #define LVA_VERIFY_LOOP 1      // fingerprint matches confirmed in a loop over the entries that have one: 1 odd instance (+0.7 %), 2 both (-3 %)
 #endif
@@ -1333,6 +1336,27 @@ __device__ __forceinline__ bool lazy_output(const Geometry& g, const LazyCtx& x,
       todo &= todo - 1u;
       const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0x3Fu, rec = (uint32_t)(rej0 >> (7 * l)) & 0x3Fu;
       uint32_t ma[2 * P], mb[2 * P];
+#if LVA_VERIFY_PAIRED
+      if constexpr (!ANCHOR) {
+        // odd step: the pair is a stay entry (the target's own list, message where the last anchor step put it) and an entry of one
+        // source list (two source lists: 5 in 100 000, the general path below).  Which is which differs per lane, where they live
+        // does not: planes in use, message buffers and the move are uniform over the workgroup -- both messages are requested
+        // together behind uniform branches only, one round trip per confirmation instead of one per piece.
+        const bool a_stay = (a8 >> 3) == 0, r_stay = (rec >> 3) == 0;
+        if (a_stay != r_stay) {
+          const uint32_t s = a_stay ? (a8 & 7u) : (rec & 7u), f6 = a_stay ? rec : a8;
+          const uint32_t* Mf = opqs(x.fb) ? opqs(x.M1) : opqs(x.M0);
+          const uint32_t* Ms = opqs(x.stale_pos1) ? (opqs(x.stale_mb) ? opqs(x.M1) : opqs(x.M0)) : Mf;
+          const uint32_t np_a = opqs(x.np_p), np_b = opqs(x.np_p1);
+          load_msg<P>(Mf + x.own + mul24(s, x.sBlk) + x.pw, x.N, x.c, np_a, ma);
+          load_msg<P>(Ms + opqs(x.src) + mul24(list_crf(x.k, f6 >> 3), x.sCrf) + mul24(f6 & 7u, x.sBlk) + x.pw, x.N, x.cp, np_b, mb);
+          push_var<2 * P>(mb, opqs(x.sh_p), x.nb_p);
+#pragma unroll
+          for (int w = 0; w < 2 * P; ++w) good &= (ma[w] == mb[w]);
+          continue;
+        }
+      }
+#endif
       lazy_message<P>(x, a8 >> 3, a8 & 7u, ANCHOR ? bp_of(a8 >> 3, a8 & 7u) : 0u, ma);
       lazy_message<P>(x, rec >> 3, rec & 7u, ANCHOR ? bp_of(rec >> 3, rec & 7u) : 0u, mb);
 #pragma unroll
