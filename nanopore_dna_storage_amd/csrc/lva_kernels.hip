@@ -50,6 +50,22 @@ __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
 __device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
 
+// An opaque copy of a register value.  Selecting between two elements of a local array,
+// `c ? a[i] : a[j]`, is folded by LLVM into a load from a selected ADDRESS, which pins the whole
+// array in scratch memory; routing the operands through an empty asm keeps them register values.
+template <typename T> __device__ __forceinline__ T opq(T x) { asm("" : "+v"(x)); return x; }
+// the same for a value that is uniform over the workgroup: stays in scalar registers
+__device__ __forceinline__ uint32_t opqs(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ const uint32_t* opqs(const uint32_t* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return (const uint32_t*)(((unsigned long long)hi << 32) | lo);
+}
+// c ? a : b on register values (both operands made opaque BEFORE the select: no control flow)
+template <typename T> __device__ __forceinline__ T selv(bool c, T a, T b) { a = opq(a); b = opq(b); return c ? a : b; }
+// c ? a : b where a and b are already plain values (scalars or registers): nothing to protect
+template <typename T> __device__ __forceinline__ T sel(bool c, T a, T b) { return c ? a : b; }
+
 struct Target {          // everything the merge of one target state needs
   uint32_t own;          // word offset of block (ring(pos), k, l=0) inside a parity buffer
   uint32_t src;          // word offset of block (ring(pos-1), crf 0, l=0) inside a parity buffer
@@ -162,6 +178,75 @@ __device__ __forceinline__ uint32_t msg_word_off(uint32_t N, uint32_t c, uint32_
 __device__ __forceinline__ uint32_t msg_word(const Geometry& g, const uint32_t* __restrict__ buf, uint32_t blk, uint32_t c,
                                              uint32_t w, uint32_t np) {
   return (w >> 1) < np ? buf[blk + 2 * g.N + msg_word_off(g.N, c, w, np)] : 0u;
+}
+
+// message of an entry (layout: msg_word_off above).  `ent` = the entry's block base + 2N (start of
+// its message region); words in planes >= np are zero and are not read
+template <int P> __device__ __forceinline__ void load_msg(const uint32_t* __restrict__ ent, uint32_t N, uint32_t c, uint32_t np,
+                                                          uint32_t (&m)[2 * P]) {
+#pragma unroll
+  for (int w = 0; w < 2 * P; ++w) m[w] = 0;
+  if (np == 1) {
+    const lva_u32x2 v = *LVA_GLOBAL(lva_u32x2, ent + 2 * c);
+    m[0] = v.x; m[1] = v.y;
+    return;
+  }
+  if constexpr (P >= 2) {
+    const lva_u32x4 v = *LVA_GLOBAL(lva_u32x4, ent + 4 * c);
+    m[0] = v.x; m[1] = v.y; m[2] = v.z; m[3] = v.w;
+    if constexpr (P >= 3) {
+      if (np == 3) {
+        const lva_u32x2 u = *LVA_GLOBAL(lva_u32x2, ent + 4 * N + 2 * c);
+        m[4] = u.x; m[5] = u.y;
+      }
+    }
+    if constexpr (P >= 4) {
+      if (np == 4) {
+        const lva_u32x4 u = *LVA_GLOBAL(lva_u32x4, ent + 4 * N + 4 * c);
+        m[4] = u.x; m[5] = u.y; m[6] = u.z; m[7] = u.w;
+      }
+    }
+  }
+}
+// non-temporal stores: written once, next read by another CU a step later (+4 % measured)
+template <int P> __device__ __forceinline__ void store_msg(uint32_t* __restrict__ ent, uint32_t N, uint32_t c, uint32_t np,
+                                                           const uint32_t (&m)[2 * P]) {
+  if (np == 1) {
+    __builtin_nontemporal_store(m[0], ent + 2 * c); __builtin_nontemporal_store(m[1], ent + 2 * c + 1);
+    return;
+  }
+  if constexpr (P >= 2) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) __builtin_nontemporal_store(m[w], ent + 4 * c + w);
+    if constexpr (P >= 3) {
+      if (np == 3) { __builtin_nontemporal_store(m[4], ent + 4 * N + 2 * c); __builtin_nontemporal_store(m[5], ent + 4 * N + 2 * c + 1); }
+    }
+    if constexpr (P >= 4) {
+      if (np == 4) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) __builtin_nontemporal_store(m[4 + w], ent + 4 * N + 4 * c + w);
+      }
+    }
+  }
+}
+// m = (m << sh) | nb, sh in {0,1,2}
+template <int W> __device__ __forceinline__ void push_bits(uint32_t (&m)[W], uint32_t sh, uint32_t nb) {
+  if (sh == 0) return;
+  uint32_t carry = nb;
+#pragma unroll
+  for (int w = 0; w < W; ++w) {
+    const uint32_t v = m[w];
+    m[w] = (v << sh) | carry;
+    carry = v >> (32 - sh);
+  }
+}
+
+// m = (m << sh) | bits with a per-lane sh in 0..31: one funnel shift per word
+template <int W> __device__ __forceinline__ void push_var(uint32_t (&m)[W], uint32_t sh, uint32_t bits) {
+  const uint32_t back = 32u - sh;
+#pragma unroll
+  for (int w = W - 1; w >= 1; --w) m[w] = sh ? __builtin_amdgcn_alignbit(m[w], m[w - 1], back) : m[w];
+  m[0] = (m[0] << sh) | bits;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -521,15 +606,15 @@ __device__ __forceinline__ void wave_target(const Geometry& g, const SlotStep& s
     }
   }
   auto cand_s = [&](uint32_t i, uint32_t j) -> float {      // i, j wavefront-uniform
-    float v = cs[0];
-#pragma unroll
-    for (uint32_t u = 1; u < 8; ++u) v = i == u ? cs[u] : v;
+    float v = opq(cs[0]);                                   // (opaque copies: a plain select chain is folded into an indexed
+#pragma unroll                                              //  load and the array then lives in scratch memory)
+    for (uint32_t u = 1; u < 8; ++u) v = i == u ? opq(cs[u]) : v;
     return rdf(v, j);
   };
   auto cand_y = [&](uint32_t i, uint32_t j) -> uint32_t {
-    uint32_t v = cy[0];
+    uint32_t v = opq(cy[0]);
 #pragma unroll
-    for (uint32_t u = 1; u < 8; ++u) v = i == u ? cy[u] : v;
+    for (uint32_t u = 1; u < 8; ++u) v = i == u ? opq(cy[u]) : v;
     return rdu(v, j);
   };
   float addv = 0.0f;                                        // transition score of list i in lane i
@@ -610,9 +695,14 @@ __device__ __forceinline__ void wave_target(const Geometry& g, const SlotStep& s
   // 3. outputs: lane a writes list entry a (:781, :799) and, if accepted, its message
   if (lane < L) {
     *reinterpret_cast<uint2*>(cur + own_sh + lane * sBlk) = lane < l ? make_uint2(f2u(as), ay) : make_uint2(kNegInfBits, 0u);
-    if (lane < l)
-      for (uint32_t w = 0; w < Wd; ++w)
-        cur[tg.own + lane * sBlk + 2 * g.N + msg_word_off(g.N, tg.c, w, tg.np_dst)] = word_of(ax >> 16, ax & 0xFFFFu, w);
+    if (lane < l) {          // the whole message in the widest pieces the layout has (not word by word: every access of a lane is its own line)
+      const uint32_t li = ax >> 16, lj = ax & 0xFFFFu;
+      const uint32_t b = (li == 0 ? tg.own : tg.src + list_crf(k, li) * sCrf) + lj * sBlk + 2 * g.N;
+      uint32_t m[8];
+      load_msg<4>(prev + b, g.N, li == 0 ? tg.c : tg.cp, li == 0 ? tg.np_dst : tg.np_src, m);
+      push_bits<8>(m, li == 0 ? 0u : tg.shift, tg.newbits);
+      store_msg<4>(cur + tg.own + lane * sBlk + 2 * g.N, g.N, tg.c, tg.np_dst, m);
+    }
   }
 }
 }  // namespace
@@ -637,7 +727,7 @@ __global__ __launch_bounds__(256) void lva_step_wave(StepArgs args, Geometry g, 
 
 // fix-up pass behind the big-list fast kernel (8 < L <= 64, and list sizes that are not a power of
 // two): wave_target over the work list; same item format and overflow behaviour as lva_step_fixup.
-__global__ __launch_bounds__(256) void lva_step_fixup_wave(StepArgs args, Geometry g, const DevCode* __restrict__ codes,
+__global__ __launch_bounds__(256, 8) void lva_step_fixup_wave(StepArgs args, Geometry g, const DevCode* __restrict__ codes,
                                                            uint32_t* __restrict__ trellis, WorkHdr* __restrict__ hdr,
                                                            const uint32_t* __restrict__ items) {
   const uint32_t par = args.step_parity;
@@ -645,30 +735,19 @@ __global__ __launch_bounds__(256) void lva_step_fixup_wave(StepArgs args, Geomet
   const bool all = hdr->overflow[par] != 0;
   if (n == 0 && !all) return;
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&hdr->total, (unsigned long long)(all ? 0xFFFFFFFFu : n));
-  Target tg;
-  if (all) {   // work list overflowed: redo the whole step, one thread per target
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-    const uint64_t per_slot = (uint64_t)args.band_max * g.N * 8, total = per_slot * args.nslots;
-    for (uint64_t idx = gid; idx < total; idx += stride) {
-      const uint32_t si = (uint32_t)(idx / per_slot);
-      const uint32_t rem = (uint32_t)(idx % per_slot);
-      SlotStep ss;
-      if (!load_slot(args, si, &ss)) continue;
-      const uint32_t c = rem % g.N, k = (rem / g.N) & 7u, pos = ss.lo + rem / (g.N * 8);
-      if (pos >= ss.hi) continue;
-      const uint32_t* prev; uint32_t* cur;
-      slot_buffers(ss, g, trellis, &prev, &cur);
-      if (resolve_target(codes[ss.orient], g, ss, pos, c, k, &tg)) exact_state(g, ss, prev, cur, tg, pos);
-    }
-    return;
-  }
+  // work list overflowed: the whole step once more on this exact path (every target of every slot; no other code in this
+  // kernel -- a call of the thread-per-target routine would cost it 114 registers and its candidate registers a place in scratch memory)
   const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u, nwaves = gridDim.x * 4;
-  for (uint32_t idx = blockIdx.x * 4 + wv; idx < n; idx += nwaves) {
-    const uint32_t it = items[idx];
-    const uint32_t mm = codes[0].m;
+  const uint32_t mm = codes[0].m;
+  const uint32_t nouter = all ? args.nslots : 1u, ninner = all ? (args.band_max << (mm + 3)) : n;   // (N = 2^m conv states, 8 crf states)
+  Target tg;
+  for (uint32_t si = 0; si < nouter; ++si)
+  for (uint32_t idx = blockIdx.x * 4 + wv; idx < ninner; idx += nwaves) {
+    const uint32_t it = all ? ((si << (mm + 11)) | idx) : items[idx];      // (uniform per wavefront; make_item's format)
     SlotStep ss;
     if (!load_slot(args, it >> (mm + 11), &ss)) continue;
     const uint32_t pos = ss.lo + ((it >> (mm + 3)) & 0xFFu), k = (it >> mm) & 7u, c = it & ((1u << mm) - 1u);
+    if (pos >= ss.hi) continue;            // (whole-step pass: band positions beyond this slot's band)
     const uint32_t* prev; uint32_t* cur;
     slot_buffers(ss, g, trellis, &prev, &cur);
     if (!resolve_target(codes[ss.orient], g, ss, pos, c, k, &tg)) continue;   // (uniform per wavefront)
@@ -717,90 +796,7 @@ namespace {
 #endif
 constexpr uint32_t TS = LVA_TS;  // source conv states per workgroup tile (workgroup = 8*TS threads); 32 measured 10 % slower
 
-// An opaque copy of a register value.  Selecting between two elements of a local array,
-// `c ? a[i] : a[j]`, is folded by LLVM into a load from a selected ADDRESS, which pins the whole
-// array in scratch memory; routing the operands through an empty asm keeps them register values.
-template <typename T> __device__ __forceinline__ T opq(T x) { asm("" : "+v"(x)); return x; }
-// the same for a value that is uniform over the workgroup: stays in scalar registers
-__device__ __forceinline__ uint32_t opqs(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
-__device__ __forceinline__ const uint32_t* opqs(const uint32_t* p) {
-  const unsigned long long v = (unsigned long long)p;
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-  return (const uint32_t*)(((unsigned long long)hi << 32) | lo);
-}
-// c ? a : b on register values (both operands made opaque BEFORE the select: no control flow)
-template <typename T> __device__ __forceinline__ T selv(bool c, T a, T b) { a = opq(a); b = opq(b); return c ? a : b; }
-// c ? a : b where a and b are already plain values (scalars or registers): nothing to protect
-template <typename T> __device__ __forceinline__ T sel(bool c, T a, T b) { return c ? a : b; }
 
-// message of an entry (layout: msg_word_off above).  `ent` = the entry's block base + 2N (start of
-// its message region); words in planes >= np are zero and are not read
-template <int P> __device__ __forceinline__ void load_msg(const uint32_t* __restrict__ ent, uint32_t N, uint32_t c, uint32_t np,
-                                                          uint32_t (&m)[2 * P]) {
-#pragma unroll
-  for (int w = 0; w < 2 * P; ++w) m[w] = 0;
-  if (np == 1) {
-    const lva_u32x2 v = *LVA_GLOBAL(lva_u32x2, ent + 2 * c);
-    m[0] = v.x; m[1] = v.y;
-    return;
-  }
-  if constexpr (P >= 2) {
-    const lva_u32x4 v = *LVA_GLOBAL(lva_u32x4, ent + 4 * c);
-    m[0] = v.x; m[1] = v.y; m[2] = v.z; m[3] = v.w;
-    if constexpr (P >= 3) {
-      if (np == 3) {
-        const lva_u32x2 u = *LVA_GLOBAL(lva_u32x2, ent + 4 * N + 2 * c);
-        m[4] = u.x; m[5] = u.y;
-      }
-    }
-    if constexpr (P >= 4) {
-      if (np == 4) {
-        const lva_u32x4 u = *LVA_GLOBAL(lva_u32x4, ent + 4 * N + 4 * c);
-        m[4] = u.x; m[5] = u.y; m[6] = u.z; m[7] = u.w;
-      }
-    }
-  }
-}
-// non-temporal stores: written once, next read by another CU a step later (+4 % measured)
-template <int P> __device__ __forceinline__ void store_msg(uint32_t* __restrict__ ent, uint32_t N, uint32_t c, uint32_t np,
-                                                           const uint32_t (&m)[2 * P]) {
-  if (np == 1) {
-    __builtin_nontemporal_store(m[0], ent + 2 * c); __builtin_nontemporal_store(m[1], ent + 2 * c + 1);
-    return;
-  }
-  if constexpr (P >= 2) {
-#pragma unroll
-    for (int w = 0; w < 4; ++w) __builtin_nontemporal_store(m[w], ent + 4 * c + w);
-    if constexpr (P >= 3) {
-      if (np == 3) { __builtin_nontemporal_store(m[4], ent + 4 * N + 2 * c); __builtin_nontemporal_store(m[5], ent + 4 * N + 2 * c + 1); }
-    }
-    if constexpr (P >= 4) {
-      if (np == 4) {
-#pragma unroll
-        for (int w = 0; w < 4; ++w) __builtin_nontemporal_store(m[4 + w], ent + 4 * N + 4 * c + w);
-      }
-    }
-  }
-}
-// m = (m << sh) | nb, sh in {0,1,2}
-template <int W> __device__ __forceinline__ void push_bits(uint32_t (&m)[W], uint32_t sh, uint32_t nb) {
-  if (sh == 0) return;
-  uint32_t carry = nb;
-#pragma unroll
-  for (int w = 0; w < W; ++w) {
-    const uint32_t v = m[w];
-    m[w] = (v << sh) | carry;
-    carry = v >> (32 - sh);
-  }
-}
-
-// m = (m << sh) | bits with a per-lane sh in 0..31: one funnel shift per word
-template <int W> __device__ __forceinline__ void push_var(uint32_t (&m)[W], uint32_t sh, uint32_t bits) {
-  const uint32_t back = 32u - sh;
-#pragma unroll
-  for (int w = W - 1; w >= 1; --w) m[w] = sh ? __builtin_amdgcn_alignbit(m[w], m[w - 1], back) : m[w];
-  m[0] = (m[0] << sh) | bits;
-}
 
 // Output phase of fast_merge for list entries [l_begin, l_end): gather the surviving messages from HBM, shift in the new
 // bits, store coalesced (:771-774, :780); every fingerprint match filed under an entry must be the same message --
