@@ -186,6 +186,14 @@ static int upload_codes(lva_decoder* d) {
     for (uint32_t p = 0; p < c.npos; ++p) dc[o].npair[p] = (uint8_t)std::max<uint32_t>(1, (c.nbits[p] + 63) / 64);
     for (int T = 0; T < 4; ++T)
       dc[o].predtab[T] = c.predtab[T].empty() ? nullptr : d->d_predtab + ((size_t)o * 4 + T) * N;
+    for (uint32_t p = 0; p < c.npos; ++p) {
+      const uint32_t q = p ? p - 1 : 0;
+      PosRec& r = dc[o].rec[p];
+      r.info = (uint32_t)dc[o].ptype[p] | (uint32_t)dc[o].ptype[q] << 8 | (uint32_t)dc[o].npair[p] << 16 | (uint32_t)dc[o].npair[q] << 24;
+      r.vmask = c.vmask[p]; r.vval = c.vval[p]; r.vmask1 = c.vmask[q]; r.vval1 = c.vval[q];
+      for (int nb = 0; nb < 4; ++nb) r.fpc[nb] = c.fpc[p][nb];
+      r.pred = dc[o].predtab[dc[o].ptype[p] & 3]; r.pred1 = dc[o].predtab[dc[o].ptype[q] & 3];
+    }
   }
   HIP_TRY(hipMalloc(&d->d_codes, sizeof dc));
   HIP_TRY(hipMemcpy(d->d_codes, dc, sizeof dc, hipMemcpyHostToDevice));

@@ -34,6 +34,19 @@ namespace lva {
 
 constexpr int kMaxSlotsLimit = 4096;   // reads in flight (the work-list item format allows 2^(21-m))
 
+struct PosRec {                  // everything a workgroup needs to know about the step INTO pos, uniform over the workgroup:
+                                 // one 64-byte scalar load instead of a chain of byte loads and pointer look-ups
+  uint32_t info;                 // ptype[pos] | ptype[pos-1] << 8 | npair[pos] << 16 | npair[pos-1] << 24   (pos = 0: its own values twice)
+  uint32_t vmask, vval;          // of pos
+  uint32_t vmask1, vval1;        // of pos-1
+  uint32_t fpc[4];               // fingerprint delta of the step into pos, by new bits
+  uint32_t pad0;
+  const uint16_t* pred;          // predtab[ptype[pos]]
+  const uint16_t* pred1;         // predtab[ptype[pos-1]]
+  uint32_t pad1[2];
+};
+static_assert(sizeof(PosRec) == 64, "PosRec is one 64-byte scalar load");
+
 struct DevCode {                 // one per orientation (0 = forward, 1 = reverse complement)
   uint32_t m, nconv, npos, init, fin;
   uint8_t ptype[256];            // block type of the step into pos
@@ -41,6 +54,7 @@ struct DevCode {                 // one per orientation (0 = forward, 1 = revers
   uint32_t vmask[256], vval[256];
   uint32_t fpc[256][4];          // fingerprint delta of the step into pos, by new bits
   const uint16_t* predtab[4];    // device pointers, [nconv] each (nullptr when unused)
+  PosRec rec[256] __attribute__((aligned(64)));
 };
 
 // One per read slot, resident in device memory: written (by lva_init_slot) when a read enters the

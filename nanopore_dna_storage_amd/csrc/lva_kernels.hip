@@ -153,6 +153,18 @@ __device__ __forceinline__ bool load_slot(const StepArgs& a, uint32_t z, SlotSte
   return ss->t != 0xFFFFFFFFu;
 }
 
+// The same with the whole record requested at once: the compiler otherwise sinks the loads of the fields behind the
+// early exits that test t and hi, and a workgroup then waits for three scalar loads one after the other.
+__device__ __forceinline__ bool load_slot_whole(const StepArgs& a, uint32_t z, SlotStep* ss) {
+  static_assert(sizeof(SlotStep) == 40, "ten words");
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(a.steps + z);
+  uint32_t w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3], w4 = p[4], w5 = p[5], w6 = p[6], w7 = p[7], w8 = p[8];
+  asm volatile("" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3), "+s"(w4), "+s"(w5), "+s"(w6), "+s"(w7), "+s"(w8));
+  ss->post_row = reinterpret_cast<const float*>(((unsigned long long)w1 << 32) | w0);
+  ss->slot = w2; ss->t = w3; ss->lo = w4; ss->hi = w5; ss->prev_hi = w6; ss->orient = w7; ss->flags = w8; ss->pad = 0;
+  return w3 != 0xFFFFFFFFu;
+}
+
 // work-list item: (((slot << 8 | band position index) << 3 | crf) << m) | conv
 __device__ __forceinline__ uint32_t make_item(uint32_t m, uint32_t z, uint32_t y, uint32_t k, uint32_t c) {
   return ((((z << 8) | y) << 3 | k) << m) | c;
@@ -205,6 +217,27 @@ template <int P> __device__ __forceinline__ void load_msg(const uint32_t* __rest
         const lva_u32x4 u = *LVA_GLOBAL(lva_u32x4, ent + 4 * N + 4 * c);
         m[4] = u.x; m[5] = u.y; m[6] = u.z; m[7] = u.w;
       }
+    }
+  }
+}
+// the same with the plane count a compile-time constant (callers that branch on a uniform np once, for several entries)
+template <int P, int NP> __device__ __forceinline__ void load_msg_np(const uint32_t* __restrict__ ent, uint32_t N, uint32_t c,
+                                                                    uint32_t (&m)[2 * P]) {
+#pragma unroll
+  for (int w = 0; w < 2 * P; ++w) m[w] = 0;
+  if constexpr (NP == 1) {
+    const lva_u32x2 v = *LVA_GLOBAL(lva_u32x2, ent + 2 * c);
+    m[0] = v.x; m[1] = v.y;
+  } else if constexpr (P >= 2) {
+    const lva_u32x4 v = *LVA_GLOBAL(lva_u32x4, ent + 4 * c);
+    m[0] = v.x; m[1] = v.y; m[2] = v.z; m[3] = v.w;
+    if constexpr (NP == 3 && P >= 3) {
+      const lva_u32x2 u = *LVA_GLOBAL(lva_u32x2, ent + 4 * N + 2 * c);
+      m[4] = u.x; m[5] = u.y;
+    }
+    if constexpr (NP == 4 && P >= 4) {
+      const lva_u32x4 u = *LVA_GLOBAL(lva_u32x4, ent + 4 * N + 4 * c);
+      m[4] = u.x; m[5] = u.y; m[6] = u.z; m[7] = u.w;
     }
   }
 }
@@ -788,6 +821,9 @@ namespace {
 #ifndef LVA_PUSH_VAR
 #define LVA_PUSH_VAR 1         // 1: message bits are pushed with ONE funnel shift per word (lazy messages: both moves at once; +4 % at m=11 L=8)
 #endif
+#ifndef LVA_ACS_PAIR
+#define LVA_ACS_PAIR 1         // L == 1: the two targets of a thread walk their chains of round trips together (acs_pair)
+#endif
 #ifndef LVA_ACS_KERNEL
 #define LVA_ACS_KERNEL 1       // L == 1 runs lva_step_acs (256-thread workgroups) instead of lva_step_fast<1,P>
 #endif
@@ -1059,17 +1095,19 @@ struct TileTarget {
   uint32_t np_dst, np_src;
   uint32_t ok;                   // bit i: list i exists (bit 0 = stay)
   uint32_t own;                  // word offset of block (ring(pos), k, l=0)
+  uint32_t base, reach;          // the base the target ends in; crf states of the source conv state that are stored
 };
 template <uint32_t TSx>
 __device__ __forceinline__ bool tile_target(const DevCode& cd, const Geometry& g, const SlotStep& ss, uint32_t pos,
                                             uint32_t tile, uint32_t tid, TileTarget* t) {
   const uint32_t N = cd.nconv;
-  const uint32_t T = cd.ptype[pos], sh = T == 0 ? 1u : 2u;
+  const PosRec pr = cd.rec[pos];                         // (uniform: scalar registers)
+  const uint32_t T = pr.info & 0xFFu, sh = T == 0 ? 1u : 2u;
   const uint32_t Tn = TSx >> sh;                         // target conv states per butterfly leg
   const uint32_t role = tid / (4 * TSx), r = (tid / TSx) & 3u, tcl = tid % TSx;
   const uint32_t c = tile * Tn + (tcl & (Tn - 1)) + (tcl / Tn) * (N >> sh);
-  if ((c & cd.vmask[pos]) != cd.vval[pos]) return false;  // :700
-  const uint32_t pk = LVA_GLOBAL(uint16_t, cd.predtab[T])[c];
+  if ((c & pr.vmask) != pr.vval) return false;           // :700
+  const uint32_t pk = LVA_GLOBAL(uint16_t, pr.pred)[c];
   uint32_t base = r;
   if (T == 0) {                                          // only two bases are reachable: r-th of them
     if (r >= 2) return false;
@@ -1084,11 +1122,19 @@ __device__ __forceinline__ bool tile_target(const DevCode& cd, const Geometry& g
   const uint32_t newest = c >> (cd.m - 1), second = (c >> (cd.m - 2)) & 1u;
   t->c = c; t->cp = cp; t->sc = cp - tile * TSx; t->sh = sh;
   t->nb = sh == 1 ? newest : (2 * second + newest);
-  t->fpc = cd.fpc[pos][t->nb];
-  t->np_dst = cd.npair[pos]; t->np_src = cd.npair[pos - 1];
-  const uint32_t reach = source_reach(cd, ss, pos, cp);
+  t->fpc = t->nb & 2u ? (t->nb & 1u ? pr.fpc[3] : pr.fpc[2]) : (t->nb & 1u ? pr.fpc[1] : pr.fpc[0]);
+  t->np_dst = (pr.info >> 16) & 0xFFu; t->np_src = pr.info >> 24;
+  uint32_t reach = 0;                                    // crf states of the source conv state that are stored (source_reach)
+  if (((cp & pr.vmask1) == pr.vval1) && (pos - 1 < ss.prev_hi)) {
+    if (pos - 1 == 0) reach = 0xFFu;
+    else {
+      const uint32_t pk1 = LVA_GLOBAL(uint16_t, pr.pred1)[cp];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) if ((pk1 >> (4 * b)) & 8u) reach |= (0x11u << b);
+    }
+  }
   const uint32_t k = base + 4 * role;
-  t->k = k;
+  t->k = k; t->base = base; t->reach = reach;
   t->own = (uint32_t)(((uint64_t)(pos % g.R) * 8 + k) * g.sCrf);
   uint32_t ok = pos < ss.prev_hi ? 1u : 0u;
   if (role == 0) {
@@ -1099,6 +1145,71 @@ __device__ __forceinline__ bool tile_target(const DevCode& cd, const Geometry& g
   }
   t->ok = ok;
   return true;
+}
+
+// L == 1, both targets of a thread (role 0: the flip target of its (base, conv); role 1: the flop target) side by side:
+// an add-compare-select is a chain of dependent round trips (stay entry -> winner -> its message -> store), and two chains
+// walked one after the other cost a workgroup twice the time of two chains walked together -- both stay entries are requested
+// first, then both winners' messages (:715-742; first maximum wins, stay before the source lists).
+template <int P>
+__device__ __forceinline__ void acs_pair(const Geometry& g, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur,
+                                         const uint2* s_src, const float* s_post, uint32_t src, bool v0, const TileTarget& t0,
+                                         bool v1, const TileTarget& t1, lva_u32x2 s0, lva_u32x2 s1) {
+  const float NEG = -INFINITY;
+  const uint32_t sCrf = g.sBlk, pw = 2 * g.N;
+  const uint32_t own0 = t0.own + 2 * t0.c, own1 = t1.own + 2 * t1.c;
+  float best0 = NEG, best1 = NEG; uint32_t bi0 = 0, bh0 = 0, bi1 = 0, bh1 = 0;
+  if (v0) {
+    const uint32_t k = t0.k;                                       // k < 4: row = k
+    const float s = u2f(s0.x) + s_post[k * 8 + k];
+    if ((t0.ok & 1u) && s > best0) { best0 = s; bh0 = s0.y; }
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+      if ((t0.ok >> i) & 1u) {
+        const uint2 v = s_src[list_crf(k, i) * TS + t0.sc];
+        const float c = u2f(v.x) + s_post[k * 8 + list_crf(k, i)];
+        if (c > best0) { best0 = c; bi0 = i; bh0 = v.y ^ t0.fpc; }
+      }
+    }
+  }
+  if (v1) {
+    const uint32_t k = t1.k;                                       // k >= 4: row 4
+    const float s = u2f(s1.x) + s_post[4 * 8 + k];
+    if ((t1.ok & 1u) && s > best1) { best1 = s; bh1 = s1.y; }
+    if ((t1.ok >> 1) & 1u) {
+      const uint2 v = s_src[list_crf(k, 1) * TS + t1.sc];
+      const float c = u2f(v.x) + s_post[4 * 8 + list_crf(k, 1)];
+      if (c > best1) { best1 = c; bi1 = 1; bh1 = v.y ^ t1.fpc; }
+    }
+  }
+  const bool w0 = v0 && best0 != NEG, w1 = v1 && best1 != NEG;
+  uint32_t m0[2 * P], m1[2 * P];
+  const uint32_t* e0 = prev + (bi0 == 0 ? t0.own : src + mul24(list_crf(t0.k, bi0), sCrf)) + pw;
+  const uint32_t* e1 = prev + (bi1 == 0 ? t1.own : src + mul24(list_crf(t1.k, bi1), sCrf)) + pw;
+  const uint32_t c0 = bi0 == 0 ? t0.c : t0.cp, c1 = bi1 == 0 ? t1.c : t1.cp;
+  const uint32_t npd = opqs(t0.np_dst), nps = opqs(t0.np_src);     // (uniform over the workgroup)
+  if (npd == nps) {     // the plane count does not change at this position (all but two or three positions): ONE uniform
+                        // branch on it, and both messages are requested before either is waited for
+    // (no test of w0 / w1: a target without a winner has bi = 0 and reads its own, allocated, stay message for nothing --
+    //  straight-line code is what lets the second request leave before the first is waited for)
+    if (npd == 1) { load_msg_np<P, 1>(e0, g.N, c0, m0); load_msg_np<P, 1>(e1, g.N, c1, m1); }
+    else if (npd == 2) { load_msg_np<P, 2>(e0, g.N, c0, m0); load_msg_np<P, 2>(e1, g.N, c1, m1); }
+    else if (npd == 3) { load_msg_np<P, 3>(e0, g.N, c0, m0); load_msg_np<P, 3>(e1, g.N, c1, m1); }
+    else { load_msg_np<P, 4>(e0, g.N, c0, m0); load_msg_np<P, 4>(e1, g.N, c1, m1); }
+  } else {
+    if (w0) load_msg<P>(e0, g.N, c0, bi0 == 0 ? npd : nps, m0);
+    if (w1) load_msg<P>(e1, g.N, c1, bi1 == 0 ? npd : nps, m1);
+  }
+  if (v0) *reinterpret_cast<uint2*>(cur + own0) = make_uint2(f2u(best0), bh0);
+  if (v1) *reinterpret_cast<uint2*>(cur + own1) = make_uint2(f2u(best1), bh1);
+  if (w0) {
+    push_bits<2 * P>(m0, bi0 == 0 ? 0u : t0.sh, t0.nb);
+    store_msg<P>(cur + t0.own + pw, g.N, t0.c, t0.np_dst, m0);
+  }
+  if (w1) {
+    push_bits<2 * P>(m1, bi1 == 0 ? 0u : t1.sh, t1.nb);
+    store_msg<P>(cur + t1.own + pw, g.N, t1.c, t1.np_dst, m1);
+  }
 }
 
 }  // namespace
@@ -1699,7 +1810,11 @@ __global__ __launch_bounds__(4 * TS) void lva_step_acs(StepArgs args, Geometry g
   __shared__ uint2 s_src[8 * TS];
   __shared__ float s_post[40];
   SlotStep ss;
+#if LVA_ACS_PAIR
+  if (!load_slot_whole(args, blockIdx.z, &ss)) return;
+#else
   if (!load_slot(args, blockIdx.z, &ss)) return;
+#endif
   const uint32_t pos = ss.lo + blockIdx.y;
   if (pos >= ss.hi) return;
   const DevCode& cd = codes[ss.orient];
@@ -1720,6 +1835,30 @@ __global__ __launch_bounds__(4 * TS) void lva_step_acs(StepArgs args, Geometry g
   }
   // stage the (score, fingerprint) pairs of 64 source conv states: 8 crf rows of 512 B, one 16-byte piece per thread
   const uint32_t src = (uint32_t)((uint64_t)((pos - 1) % g.R) * 8 * g.sCrf);
+#if LVA_ACS_PAIR
+  // Every request that does not depend on another goes out before anything is waited for: the staging piece, the posteriors,
+  // the tables of this thread's targets and -- behind those -- their stay entries.  What is left of the chain of round trips:
+  // (slot record) -> (staging | tables -> stay entries) -> barrier -> winners -> their messages -> stores.
+  const uint32_t rowi = tid / (TS / 2), lane2 = tid % (TS / 2);
+  const lva_u32x4 sv = *LVA_GLOBAL(lva_u32x4, prev + src + (uint64_t)rowi * g.sBlk + 2 * (tile * TS) + 4 * lane2);
+  float pv = 0.0f;
+  if (tid < 40) pv = LVA_GLOBAL(float, ss.post_row)[tid];
+  TileTarget t0;
+  const bool valid = tile_target<TS>(cd, g, ss, pos, tile, tid, &t0);   // role 0: the flip target of (base, conv)
+  TileTarget t1 = t0;                                                    // role 1: the flop target of the same (base, conv)
+  t1.k = t0.base + 4; t1.own = t0.own + 4u * (uint32_t)g.sCrf;
+  t1.ok = (t0.ok & 1u) | (((t0.reach >> t0.base) & 1u) << 1);
+  lva_u32x2 s0 = {kNegInfBits, 0u}, s1 = {kNegInfBits, 0u};
+  if (valid && (t0.ok & 1u)) {           // (the stay bit is the same for both)
+    s0 = *LVA_GLOBAL(lva_u32x2, prev + t0.own + 2 * t0.c);
+    s1 = *LVA_GLOBAL(lva_u32x2, prev + t1.own + 2 * t1.c);
+  }
+  *reinterpret_cast<lva_u32x4*>(&s_src[rowi * TS + 2 * lane2]) = sv;
+  if (tid < 40) s_post[tid] = pv;
+  __syncthreads();
+  if (!valid) return;
+  acs_pair<P>(g, prev, cur, s_src, s_post, src, true, t0, true, t1, s0, s1);
+#else
   {
     const uint32_t rowi = tid / (TS / 2), lane2 = tid % (TS / 2);
     const uint4 v = *reinterpret_cast<const uint4*>(prev + src + (uint64_t)rowi * g.sBlk + 2 * (tile * TS) + 4 * lane2);
@@ -1732,6 +1871,7 @@ __global__ __launch_bounds__(4 * TS) void lva_step_acs(StepArgs args, Geometry g
     fast_acs<P, 8>(g, prev, cur, s_src, s_post, t.k, t.c, t.cp, t.sc, t.own, src, t.ok, t.sh, t.nb, t.fpc, t.np_dst, t.np_src);
   if (tile_target<TS>(cd, g, ss, pos, tile, tid + 4 * TS, &t))       // role 1: the flop target
     fast_acs<P, 2>(g, prev, cur, s_src, s_post, t.k, t.c, t.cp, t.sc, t.own, src, t.ok, t.sh, t.nb, t.fpc, t.np_dst, t.np_src);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
