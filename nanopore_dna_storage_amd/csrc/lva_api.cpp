@@ -192,6 +192,7 @@ static int upload_codes(lva_decoder* d) {
       r.info = (uint32_t)dc[o].ptype[p] | (uint32_t)dc[o].ptype[q] << 8 | (uint32_t)dc[o].npair[p] << 16 | (uint32_t)dc[o].npair[q] << 24;
       r.vmask = c.vmask[p]; r.vval = c.vval[p]; r.vmask1 = c.vmask[q]; r.vval1 = c.vval[q];
       for (int nb = 0; nb < 4; ++nb) r.fpc[nb] = c.fpc[p][nb];
+      r.np2 = p >= 2 ? dc[o].npair[p - 2] : 1u;
       r.pred = dc[o].predtab[dc[o].ptype[p] & 3]; r.pred1 = dc[o].predtab[dc[o].ptype[q] & 3];
     }
   }

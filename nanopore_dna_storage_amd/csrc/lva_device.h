@@ -40,7 +40,7 @@ struct PosRec {                  // everything a workgroup needs to know about t
   uint32_t vmask, vval;          // of pos
   uint32_t vmask1, vval1;        // of pos-1
   uint32_t fpc[4];               // fingerprint delta of the step into pos, by new bits
-  uint32_t pad0;
+  uint32_t np2;                  // npair[pos-2] (1 when pos < 2)
   const uint16_t* pred;          // predtab[ptype[pos]]
   const uint16_t* pred1;         // predtab[ptype[pos-1]]
   uint32_t pad1[2];

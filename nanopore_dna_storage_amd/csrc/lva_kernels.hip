@@ -821,6 +821,12 @@ namespace {
 #ifndef LVA_PUSH_VAR
 #define LVA_PUSH_VAR 1         // 1: message bits are pushed with ONE funnel shift per word (lazy messages: both moves at once; +4 % at m=11 L=8)
 #endif
+#ifndef LVA_LAZY_POSREC
+#define LVA_LAZY_POSREC 1      // lazy_ctx reads the position record (one scalar load) instead of five byte tables
+#endif
+#ifndef LVA_LAZY_HOIST
+#define LVA_LAZY_HOIST 0       // lazy kernels: slot record in one load, target tables requested before the staging loads are waited for
+#endif
 #ifndef LVA_ACS_PAIR
 #define LVA_ACS_PAIR 1         // L == 1: the two targets of a thread walk their chains of round trips together (acs_pair)
 #endif
@@ -1386,6 +1392,17 @@ __device__ __forceinline__ void lazy_ctx(const DevCode& cd, const Geometry& g, c
   x->c = c; x->cp = cp; x->k = k; x->own = own;
   x->src = (uint32_t)((uint64_t)((pos + g.R - 1) % g.R) * 8 * g.sCrf);
   x->src2 = (uint32_t)((uint64_t)((pos + g.R - 2) % g.R) * 8 * g.sCrf);
+#if LVA_LAZY_POSREC
+  const PosRec pr = cd.rec[pos];           // (one scalar load; pos >= 1 here)
+  const uint32_t Tp = pr.info & 0xFFu;
+  x->sh_p = Tp == 0 ? 1u : 2u;
+  x->nb_p = x->sh_p == 1 ? (c >> (cd.m - 1)) : (2 * ((c >> (cd.m - 2)) & 1u) + (c >> (cd.m - 1)));
+  const uint32_t Tq = (pr.info >> 8) & 0xFFu;
+  x->sh_q = Tq == 0 ? 1u : 2u;
+  x->nb_q = x->sh_q == 1 ? (cp >> (cd.m - 1)) : (2 * ((cp >> (cd.m - 2)) & 1u) + (cp >> (cd.m - 1)));
+  x->pk1 = (pos >= 2 && !(ss.t & 1u)) ? (uint32_t)LVA_GLOBAL(uint16_t, pr.pred1)[cp] : 0u;
+  x->np_p = (pr.info >> 16) & 0xFFu; x->np_p1 = pr.info >> 24; x->np_p2 = pr.np2;
+#else
   const uint32_t Tp = cd.ptype[pos];
   x->sh_p = Tp == 0 ? 1u : 2u;
   x->nb_p = x->sh_p == 1 ? (c >> (cd.m - 1)) : (2 * ((c >> (cd.m - 2)) & 1u) + (c >> (cd.m - 1)));
@@ -1394,6 +1411,7 @@ __device__ __forceinline__ void lazy_ctx(const DevCode& cd, const Geometry& g, c
   x->nb_q = x->sh_q == 1 ? (cp >> (cd.m - 1)) : (2 * ((cp >> (cd.m - 2)) & 1u) + (cp >> (cd.m - 1)));
   x->pk1 = (pos >= 2 && !(ss.t & 1u)) ? (uint32_t)LVA_GLOBAL(uint16_t, cd.predtab[Tq])[cp] : 0u;
   x->np_p = cd.npair[pos]; x->np_p1 = pos >= 1 ? cd.npair[pos - 1] : 1u; x->np_p2 = pos >= 2 ? cd.npair[pos - 2] : 1u;
+#endif
   x->t = ss.t; x->fb = ((ss.t - 1u) >> 1) & 1u;
   x->stale_pos1 = (pos == ss.lo) && (ss.flags & 1u);
   x->stale_mb = (ss.flags >> 1) & 1u;
@@ -1550,7 +1568,11 @@ __global__ __launch_bounds__(8 * TS, ANCHOR ? LVA_LAZY_ANCHOR_MINWAVES : LVA_LAZ
     hdr->overflow[args.step_parity ^ 1u] = 0;
   }
   SlotStep ss;
+#if LVA_LAZY_HOIST
+  if (!load_slot_whole(args, blockIdx.z, &ss)) return;
+#else
   if (!load_slot(args, blockIdx.z, &ss)) return;
+#endif
   if (!(ss.t & 1u) != ANCHOR) return;
   const uint32_t pos = ss.lo + blockIdx.y;
   if (pos >= ss.hi) return;
@@ -1578,6 +1600,10 @@ __global__ __launch_bounds__(8 * TS, ANCHOR ? LVA_LAZY_ANCHOR_MINWAVES : LVA_LAZ
 
   // ---- stage the (score, fingerprint) pairs of 64 source conv states (and, for an anchor step, their back-pointer bytes) ----
   const uint32_t src = (uint32_t)((uint64_t)((pos - 1) % g.R) * 8 * g.sCrf);
+#if LVA_LAZY_HOIST
+  TileTarget t;                            // the table look-ups of this thread's target travel with the staging loads
+  const bool valid = tile_target<TS>(cd, g, ss, pos, tile, tid, &t);
+#endif
   for (uint32_t chunk = tid; chunk < 8u * LL * (TS / 2); chunk += 8u * TS) {
     const uint32_t rowi = chunk / (TS / 2), lane2 = chunk % (TS / 2);       // rowi = crf * LL + l
     const uint4 v = *reinterpret_cast<const uint4*>(prev + src + (uint64_t)(rowi / LL) * g.sCrf + (uint64_t)(rowi % LL) * g.sBlk +
@@ -1595,8 +1621,12 @@ __global__ __launch_bounds__(8 * TS, ANCHOR ? LVA_LAZY_ANCHOR_MINWAVES : LVA_LAZ
   if (tid < 40) s_post[tid] = LVA_GLOBAL(float, ss.post_row)[tid];
   __syncthreads();
 
+#if LVA_LAZY_HOIST
+  if (!valid) return;
+#else
   TileTarget t;
   if (!tile_target<TS>(cd, g, ss, pos, tile, tid, &t)) return;
+#endif
   // an anchor step needs the back-pointer bytes of its own (stay) list: requested now, used after the merge
   unsigned long long own_bp = 0;
   if (anchor && ss.t != 0 && (t.ok & 1u)) {
