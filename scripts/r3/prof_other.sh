@@ -7,3 +7,4 @@ run m14 --mem-conv 14 --rate 7 --slots 8 --steps 2 --warmup 1 --pool 32
 run big64 --list-size 64 --slots 8 --steps 1 --warmup 1 --pool 16
 run m8 --mem-conv 8 --rate 3 --msg-len 164 --steps 3 --warmup 1 --pool 1024
 run m6 --mem-conv 6 --rate 1 --list-size 1 --steps 3 --warmup 1 --pool 4096
+run m11L1 --list-size 1 --steps 2 --warmup 1 --pool 512
