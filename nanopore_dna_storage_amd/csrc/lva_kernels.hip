@@ -1196,12 +1196,14 @@ __device__ __forceinline__ void acs_pair(const Geometry& g, const uint32_t* __re
   const uint32_t npd = opqs(t0.np_dst), nps = opqs(t0.np_src);     // (uniform over the workgroup)
   if (npd == nps) {     // the plane count does not change at this position (all but two or three positions): ONE uniform
                         // branch on it, and both messages are requested before either is waited for
-    // (no test of w0 / w1: a target without a winner has bi = 0 and reads its own, allocated, stay message for nothing --
-    //  straight-line code is what lets the second request leave before the first is waited for)
-    if (npd == 1) { load_msg_np<P, 1>(e0, g.N, c0, m0); load_msg_np<P, 1>(e1, g.N, c1, m1); }
-    else if (npd == 2) { load_msg_np<P, 2>(e0, g.N, c0, m0); load_msg_np<P, 2>(e1, g.N, c1, m1); }
-    else if (npd == 3) { load_msg_np<P, 3>(e0, g.N, c0, m0); load_msg_np<P, 3>(e1, g.N, c1, m1); }
-    else { load_msg_np<P, 4>(e0, g.N, c0, m0); load_msg_np<P, 4>(e1, g.N, c1, m1); }
+    // (ONE test for both: straight-line code is what lets the second request leave before the first is waited for; a target
+    //  without a winner beside one that has a winner has bi = 0 and reads its own, allocated, stay message for nothing)
+    if (w0 || w1) {
+      if (npd == 1) { load_msg_np<P, 1>(e0, g.N, c0, m0); load_msg_np<P, 1>(e1, g.N, c1, m1); }
+      else if (npd == 2) { load_msg_np<P, 2>(e0, g.N, c0, m0); load_msg_np<P, 2>(e1, g.N, c1, m1); }
+      else if (npd == 3) { load_msg_np<P, 3>(e0, g.N, c0, m0); load_msg_np<P, 3>(e1, g.N, c1, m1); }
+      else { load_msg_np<P, 4>(e0, g.N, c0, m0); load_msg_np<P, 4>(e1, g.N, c1, m1); }
+    }
   } else {
     if (w0) load_msg<P>(e0, g.N, c0, bi0 == 0 ? npd : nps, m0);
     if (w1) load_msg<P>(e1, g.N, c1, bi1 == 0 ? npd : nps, m1);
