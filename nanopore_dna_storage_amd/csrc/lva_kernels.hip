@@ -821,6 +821,9 @@ namespace {
 #ifndef LVA_PUSH_VAR
 #define LVA_PUSH_VAR 1         // 1: message bits are pushed with ONE funnel shift per word (lazy messages: both moves at once; +4 % at m=11 L=8)
 #endif
+#ifndef LVA_LAZY_PK1
+#define LVA_LAZY_PK1 1         // anchor instance: the predecessor word of the source conv state is kept from tile_target instead of read again
+#endif
 #ifndef LVA_LAZY_POSREC
 #define LVA_LAZY_POSREC 1      // lazy_ctx reads the position record (one scalar load) instead of five byte tables
 #endif
@@ -1102,6 +1105,7 @@ struct TileTarget {
   uint32_t ok;                   // bit i: list i exists (bit 0 = stay)
   uint32_t own;                  // word offset of block (ring(pos), k, l=0)
   uint32_t base, reach;          // the base the target ends in; crf states of the source conv state that are stored
+  uint32_t pk1;                  // predecessor-table word of the source conv state at pos-1 (0 where reach did not need it)
 };
 template <uint32_t TSx>
 __device__ __forceinline__ bool tile_target(const DevCode& cd, const Geometry& g, const SlotStep& ss, uint32_t pos,
@@ -1131,10 +1135,12 @@ __device__ __forceinline__ bool tile_target(const DevCode& cd, const Geometry& g
   t->fpc = t->nb & 2u ? (t->nb & 1u ? pr.fpc[3] : pr.fpc[2]) : (t->nb & 1u ? pr.fpc[1] : pr.fpc[0]);
   t->np_dst = (pr.info >> 16) & 0xFFu; t->np_src = pr.info >> 24;
   uint32_t reach = 0;                                    // crf states of the source conv state that are stored (source_reach)
+  t->pk1 = 0;
   if (((cp & pr.vmask1) == pr.vval1) && (pos - 1 < ss.prev_hi)) {
     if (pos - 1 == 0) reach = 0xFFu;
     else {
       const uint32_t pk1 = LVA_GLOBAL(uint16_t, pr.pred1)[cp];
+      t->pk1 = pk1;
 #pragma unroll
       for (int b = 0; b < 4; ++b) if ((pk1 >> (4 * b)) & 8u) reach |= (0x11u << b);
     }
@@ -1387,7 +1393,7 @@ __device__ __forceinline__ void lazy_message(const LazyCtx& x, uint32_t i, uint3
 }
 
 __device__ __forceinline__ void lazy_ctx(const DevCode& cd, const Geometry& g, const SlotStep& ss, const uint32_t* slot_base, uint32_t pos,
-                                         uint32_t c, uint32_t cp, uint32_t k, uint32_t own, LazyCtx* x) {
+                                         uint32_t c, uint32_t cp, uint32_t k, uint32_t own, LazyCtx* x, int pk1_known = -1) {
   x->M0 = slot_base; x->M1 = slot_base + g.sPar;
   x->bp_prev = reinterpret_cast<const uint8_t*>(slot_base + (uint64_t)(ss.t & 1u) * g.sPar);
   x->N = g.N; x->sBlk = g.sBlk; x->sCrf = (uint32_t)g.sCrf; x->pw = 2 * g.N; x->m = cd.m;
@@ -1402,7 +1408,8 @@ __device__ __forceinline__ void lazy_ctx(const DevCode& cd, const Geometry& g, c
   const uint32_t Tq = (pr.info >> 8) & 0xFFu;
   x->sh_q = Tq == 0 ? 1u : 2u;
   x->nb_q = x->sh_q == 1 ? (cp >> (cd.m - 1)) : (2 * ((cp >> (cd.m - 2)) & 1u) + (cp >> (cd.m - 1)));
-  x->pk1 = (pos >= 2 && !(ss.t & 1u)) ? (uint32_t)LVA_GLOBAL(uint16_t, pr.pred1)[cp] : 0u;
+  // (pk1_known >= 0: the caller's tile_target has read this word already -- wherever the target has a source list at all)
+  x->pk1 = pk1_known >= 0 ? (uint32_t)pk1_known : (pos >= 2 && !(ss.t & 1u)) ? (uint32_t)LVA_GLOBAL(uint16_t, pr.pred1)[cp] : 0u;
   x->np_p = (pr.info >> 16) & 0xFFu; x->np_p1 = pr.info >> 24; x->np_p2 = pr.np2;
 #else
   const uint32_t Tp = cd.ptype[pos];
@@ -1654,7 +1661,11 @@ __global__ __launch_bounds__(8 * TS, ANCHOR ? LVA_LAZY_ANCHOR_MINWAVES : LVA_LAZ
                     : fast_merge_core<LL, 2>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &rej1, &lc);
   if (!why) {
     LazyCtx x;
+#if LVA_LAZY_PK1
+    lazy_ctx(cd, g, ss, slot_base, pos, t.c, t.cp, t.k, t.own, &x, ANCHOR ? (int)t.pk1 : 0);
+#else
     lazy_ctx(cd, g, ss, slot_base, pos, t.c, t.cp, t.k, t.own, &x);
+#endif
     if (!lazy_output<LL, P, ANCHOR>(g, x, cur, mout, s_bp, t.sc, own_bp, asrc, rej0, rej1, lc)) why = 4;
 #if LVA_ABLATE == 7       // the output phase once more (the same stores again: idempotent)
     asm volatile("" ::: "memory");
