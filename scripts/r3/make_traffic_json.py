@@ -15,7 +15,8 @@ src, dst = sys.argv[1], sys.argv[2]
 
 
 def counters(name):
-    f = glob.glob("%s/%s/*/*counter_collection.csv" % (src, name))[0]
+    import os
+    f = max(glob.glob("%s/%s/*/*counter_collection.csv" % (src, name)), key=os.path.getmtime)   # (the directory collects every run: newest)
     df = pd.read_csv(f)
     df["k"] = df["Kernel_Name"].str.extract(r"(lva_step_lazy(?:_fused)?<[^>]*>)")[0]
     return df.groupby(["k", "Counter_Name"])["Counter_Value"].mean().unstack()
