@@ -821,18 +821,6 @@ namespace {
 #ifndef LVA_PUSH_VAR
 #define LVA_PUSH_VAR 1         // 1: message bits are pushed with ONE funnel shift per word (lazy messages: both moves at once; +4 % at m=11 L=8)
 #endif
-#ifndef LVA_LAZY_PK1
-#define LVA_LAZY_PK1 1         // anchor instance: the predecessor word of the source conv state is kept from tile_target instead of read again
-#endif
-#ifndef LVA_LAZY_POSREC
-#define LVA_LAZY_POSREC 1      // lazy_ctx reads the position record (one scalar load) instead of five byte tables
-#endif
-#ifndef LVA_LAZY_HOIST
-#define LVA_LAZY_HOIST 0       // lazy kernels: slot record in one load, target tables requested before the staging loads are waited for
-#endif
-#ifndef LVA_ACS_PAIR
-#define LVA_ACS_PAIR 1         // L == 1: the two targets of a thread walk their chains of round trips together (acs_pair)
-#endif
 #ifndef LVA_ACS_KERNEL
 #define LVA_ACS_KERNEL 1       // L == 1 runs lva_step_acs (256-thread workgroups) instead of lva_step_fast<1,P>
 #endif
@@ -1400,7 +1388,6 @@ __device__ __forceinline__ void lazy_ctx(const DevCode& cd, const Geometry& g, c
   x->c = c; x->cp = cp; x->k = k; x->own = own;
   x->src = (uint32_t)((uint64_t)((pos + g.R - 1) % g.R) * 8 * g.sCrf);
   x->src2 = (uint32_t)((uint64_t)((pos + g.R - 2) % g.R) * 8 * g.sCrf);
-#if LVA_LAZY_POSREC
   const PosRec pr = cd.rec[pos];           // (one scalar load; pos >= 1 here)
   const uint32_t Tp = pr.info & 0xFFu;
   x->sh_p = Tp == 0 ? 1u : 2u;
@@ -1411,16 +1398,6 @@ __device__ __forceinline__ void lazy_ctx(const DevCode& cd, const Geometry& g, c
   // (pk1_known >= 0: the caller's tile_target has read this word already -- wherever the target has a source list at all)
   x->pk1 = pk1_known >= 0 ? (uint32_t)pk1_known : (pos >= 2 && !(ss.t & 1u)) ? (uint32_t)LVA_GLOBAL(uint16_t, pr.pred1)[cp] : 0u;
   x->np_p = (pr.info >> 16) & 0xFFu; x->np_p1 = pr.info >> 24; x->np_p2 = pr.np2;
-#else
-  const uint32_t Tp = cd.ptype[pos];
-  x->sh_p = Tp == 0 ? 1u : 2u;
-  x->nb_p = x->sh_p == 1 ? (c >> (cd.m - 1)) : (2 * ((c >> (cd.m - 2)) & 1u) + (c >> (cd.m - 1)));
-  const uint32_t Tq = pos >= 1 ? cd.ptype[pos - 1] : 0u;
-  x->sh_q = Tq == 0 ? 1u : 2u;
-  x->nb_q = x->sh_q == 1 ? (cp >> (cd.m - 1)) : (2 * ((cp >> (cd.m - 2)) & 1u) + (cp >> (cd.m - 1)));
-  x->pk1 = (pos >= 2 && !(ss.t & 1u)) ? (uint32_t)LVA_GLOBAL(uint16_t, cd.predtab[Tq])[cp] : 0u;
-  x->np_p = cd.npair[pos]; x->np_p1 = pos >= 1 ? cd.npair[pos - 1] : 1u; x->np_p2 = pos >= 2 ? cd.npair[pos - 2] : 1u;
-#endif
   x->t = ss.t; x->fb = ((ss.t - 1u) >> 1) & 1u;
   x->stale_pos1 = (pos == ss.lo) && (ss.flags & 1u);
   x->stale_mb = (ss.flags >> 1) & 1u;
@@ -1577,11 +1554,7 @@ __global__ __launch_bounds__(8 * TS, ANCHOR ? LVA_LAZY_ANCHOR_MINWAVES : LVA_LAZ
     hdr->overflow[args.step_parity ^ 1u] = 0;
   }
   SlotStep ss;
-#if LVA_LAZY_HOIST
-  if (!load_slot_whole(args, blockIdx.z, &ss)) return;
-#else
   if (!load_slot(args, blockIdx.z, &ss)) return;
-#endif
   if (!(ss.t & 1u) != ANCHOR) return;
   const uint32_t pos = ss.lo + blockIdx.y;
   if (pos >= ss.hi) return;
@@ -1609,10 +1582,6 @@ __global__ __launch_bounds__(8 * TS, ANCHOR ? LVA_LAZY_ANCHOR_MINWAVES : LVA_LAZ
 
   // ---- stage the (score, fingerprint) pairs of 64 source conv states (and, for an anchor step, their back-pointer bytes) ----
   const uint32_t src = (uint32_t)((uint64_t)((pos - 1) % g.R) * 8 * g.sCrf);
-#if LVA_LAZY_HOIST
-  TileTarget t;                            // the table look-ups of this thread's target travel with the staging loads
-  const bool valid = tile_target<TS>(cd, g, ss, pos, tile, tid, &t);
-#endif
   for (uint32_t chunk = tid; chunk < 8u * LL * (TS / 2); chunk += 8u * TS) {
     const uint32_t rowi = chunk / (TS / 2), lane2 = chunk % (TS / 2);       // rowi = crf * LL + l
     const uint4 v = *reinterpret_cast<const uint4*>(prev + src + (uint64_t)(rowi / LL) * g.sCrf + (uint64_t)(rowi % LL) * g.sBlk +
@@ -1630,12 +1599,8 @@ __global__ __launch_bounds__(8 * TS, ANCHOR ? LVA_LAZY_ANCHOR_MINWAVES : LVA_LAZ
   if (tid < 40) s_post[tid] = LVA_GLOBAL(float, ss.post_row)[tid];
   __syncthreads();
 
-#if LVA_LAZY_HOIST
-  if (!valid) return;
-#else
   TileTarget t;
   if (!tile_target<TS>(cd, g, ss, pos, tile, tid, &t)) return;
-#endif
   // an anchor step needs the back-pointer bytes of its own (stay) list: requested now, used after the merge
   unsigned long long own_bp = 0;
   if (anchor && ss.t != 0 && (t.ok & 1u)) {
@@ -1661,11 +1626,7 @@ __global__ __launch_bounds__(8 * TS, ANCHOR ? LVA_LAZY_ANCHOR_MINWAVES : LVA_LAZ
                     : fast_merge_core<LL, 2>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &rej1, &lc);
   if (!why) {
     LazyCtx x;
-#if LVA_LAZY_PK1
     lazy_ctx(cd, g, ss, slot_base, pos, t.c, t.cp, t.k, t.own, &x, ANCHOR ? (int)t.pk1 : 0);
-#else
-    lazy_ctx(cd, g, ss, slot_base, pos, t.c, t.cp, t.k, t.own, &x);
-#endif
     if (!lazy_output<LL, P, ANCHOR>(g, x, cur, mout, s_bp, t.sc, own_bp, asrc, rej0, rej1, lc)) why = 4;
 #if LVA_ABLATE == 7       // the output phase once more (the same stores again: idempotent)
     asm volatile("" ::: "memory");
@@ -1853,11 +1814,7 @@ __global__ __launch_bounds__(4 * TS) void lva_step_acs(StepArgs args, Geometry g
   __shared__ uint2 s_src[8 * TS];
   __shared__ float s_post[40];
   SlotStep ss;
-#if LVA_ACS_PAIR
   if (!load_slot_whole(args, blockIdx.z, &ss)) return;
-#else
-  if (!load_slot(args, blockIdx.z, &ss)) return;
-#endif
   const uint32_t pos = ss.lo + blockIdx.y;
   if (pos >= ss.hi) return;
   const DevCode& cd = codes[ss.orient];
@@ -1878,7 +1835,6 @@ __global__ __launch_bounds__(4 * TS) void lva_step_acs(StepArgs args, Geometry g
   }
   // stage the (score, fingerprint) pairs of 64 source conv states: 8 crf rows of 512 B, one 16-byte piece per thread
   const uint32_t src = (uint32_t)((uint64_t)((pos - 1) % g.R) * 8 * g.sCrf);
-#if LVA_ACS_PAIR
   // Every request that does not depend on another goes out before anything is waited for: the staging piece, the posteriors,
   // the tables of this thread's targets and -- behind those -- their stay entries.  What is left of the chain of round trips:
   // (slot record) -> (staging | tables -> stay entries) -> barrier -> winners -> their messages -> stores.
@@ -1901,20 +1857,6 @@ __global__ __launch_bounds__(4 * TS) void lva_step_acs(StepArgs args, Geometry g
   __syncthreads();
   if (!valid) return;
   acs_pair<P>(g, prev, cur, s_src, s_post, src, true, t0, true, t1, s0, s1);
-#else
-  {
-    const uint32_t rowi = tid / (TS / 2), lane2 = tid % (TS / 2);
-    const uint4 v = *reinterpret_cast<const uint4*>(prev + src + (uint64_t)rowi * g.sBlk + 2 * (tile * TS) + 4 * lane2);
-    *reinterpret_cast<uint4*>(&s_src[rowi * TS + 2 * lane2]) = v;
-  }
-  if (tid < 40) s_post[tid] = LVA_GLOBAL(float, ss.post_row)[tid];
-  __syncthreads();
-  TileTarget t;
-  if (tile_target<TS>(cd, g, ss, pos, tile, tid, &t))                // role 0: the flip target of (base, conv)
-    fast_acs<P, 8>(g, prev, cur, s_src, s_post, t.k, t.c, t.cp, t.sc, t.own, src, t.ok, t.sh, t.nb, t.fpc, t.np_dst, t.np_src);
-  if (tile_target<TS>(cd, g, ss, pos, tile, tid + 4 * TS, &t))       // role 1: the flop target
-    fast_acs<P, 2>(g, prev, cur, s_src, s_post, t.k, t.c, t.cp, t.sc, t.own, src, t.ok, t.sh, t.nb, t.fpc, t.np_dst, t.np_src);
-#endif
 }
 
 // ---------------------------------------------------------------------------------------
