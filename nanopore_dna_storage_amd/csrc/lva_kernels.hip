@@ -1802,10 +1802,11 @@ __global__ __launch_bounds__(256) void lva_step_fixup_lazy(StepArgs args, Geomet
 
 // ---------------------------------------------------------------------------------------
 // L == 1 (plain Viterbi, :715-742): the same butterfly tile with HALF the threads -- thread (base r, target conv)
-// does the flip target of its (conv, base) and then the flop target.  An add-compare-select is a handful of
-// instructions behind a chain of dependent round trips (slot -> band -> tables -> staging -> barrier -> gather ->
-// store), so what matters is how many tiles a CU has in flight: 256-thread workgroups double that (8 instead of 4
-// per CU).  No ties to resolve (first maximum wins), no work list.
+// does the flip target of its (conv, base) AND the flop target, side by side (acs_pair).  An add-compare-select is a
+// handful of instructions behind a chain of dependent round trips, so what matters is how many tiles a CU has in
+// flight (256-thread workgroups: 8 instead of 4 per CU) and how short the chain is: slot record (one load) ->
+// staging | position record -> tables -> stay entries, all requested before the first wait -> barrier -> winners ->
+// their messages (both together) -> stores.  No ties to resolve (first maximum wins), no work list.
 // grid: x = tiles of 64 source conv states, y = band position index, z = slot index.
 // ---------------------------------------------------------------------------------------
 template <int P>
