@@ -4,6 +4,7 @@ of each (helper.decode_list_CRC_index) and prints the reference's four tallies. 
 the script are flags here (same names, lower case)."""
 import argparse
 import os
+import re
 import sys
 
 from . import helper
@@ -23,7 +24,7 @@ def read_lists(directory):
     """every list_<i> file of the directory, in os.listdir order like the reference (:24-30) -> [(name, [entries])]"""
     out = []
     for filename in os.listdir(directory):
-        if not filename.startswith("list_"):
+        if not re.fullmatch(r"list_\d+", filename):      # (the reference takes every name starting with list_: :26)
             continue
         with open(os.path.join(directory, filename)) as f:
             out.append((filename, [ln.rstrip("\n") for ln in f.readlines()]))

@@ -793,58 +793,29 @@ __global__ __launch_bounds__(256, 8) void lva_step_fixup_wave(StepArgs args, Geo
 // ---------------------------------------------------------------------------------------
 namespace {
 
-#ifndef LVA_LAZY_ODD_MINWAVES
-#define LVA_LAZY_ODD_MINWAVES 8
-#endif
-#ifndef LVA_LAZY_ANCHOR_MINWAVES
-#define LVA_LAZY_ANCHOR_MINWAVES 8   // the anchor instance held to 64 registers (its own count: 66): four workgroups per CU instead of
-#endif                               // three for one 8-byte spill outside the merge loop: +1.6 % at m=11, +3.2 % at m=14 (round 3)
-#ifndef LVA_REJ_SLOTS
-#define LVA_REJ_SLOTS 1
-#endif
-#ifndef LVA_FIXUP_LAZY_GRID
-#define LVA_FIXUP_LAZY_GRID 4096   // workgroups (of four wavefronts) of lva_step_fixup_lazy
-#endif
-#ifndef LVA_VERIFY_PAIRED
-#define LVA_VERIFY_PAIRED 1      // odd instance: both messages of a confirmation requested together behind uniform branches (+1.2 %)
-#endif
-#ifndef LVA_VERIFY_LOOP
-#define LVA_VERIFY_LOOP 1      // fingerprint matches confirmed in a loop over the entries that have one: 1 odd instance (+0.7 %), 2 both (-3 %)
-#endif
-#ifndef LVA_ABLATE
-#define LVA_ABLATE 0           // timing-only builds of the lazy pair.  Results stay correct: 6 = the merge once more without its
-#endif                         // stores, 7 = the output phase once more.  Results WRONG: 2 = merge loop capped at 8 iterations, 3 = no
-                               // confirmation of fingerprint matches, 5 = no merge and no output at all
-#ifndef LVA_LAZY_GB
-#define LVA_LAZY_GB 2
-#endif
-#ifndef LVA_PUSH_VAR
-#define LVA_PUSH_VAR 1         // 1: message bits are pushed with ONE funnel shift per word (lazy messages: both moves at once; +4 % at m=11 L=8)
-#endif
-#ifndef LVA_ACS_KERNEL
-#define LVA_ACS_KERNEL 1       // L == 1 runs lva_step_acs (256-thread workgroups) instead of lva_step_fast<1,P>
-#endif
-#ifndef LVA_TS
-#define LVA_TS 64
-#endif
-constexpr uint32_t TS = LVA_TS;  // source conv states per workgroup tile (workgroup = 8*TS threads); 32 measured 10 % slower
+// Tuning constants, each the measured best of its experiment series (DESIGN_HISTORY.md; the rejected variants are kept as
+// diffs under scripts/experiments/, not as switches in this file).
+constexpr uint32_t TS = 64;              // source conv states per workgroup tile (workgroup = 8*TS threads); 32 measured 10 % slower
+constexpr int kLazyMinWaves = 8;         // both lazy instances held to 64 registers: four 512-thread workgroups per CU (the anchor
+                                         // instance's own count is 66: one 8-byte spill outside the merge loop, +1.6 % at m=11)
+constexpr uint32_t kFixupLazyGrid = 4096;   // workgroups (of four wavefronts) of lva_step_fixup_lazy
+constexpr int kLazyInFlight = 2;         // anchor instance: entries whose message loads are in flight together (3: -3 %, 4: -12 %)
 
 
 
-// Output phase of fast_merge for list entries [l_begin, l_end): gather the surviving messages from HBM, shift in the new
-// bits, store coalesced (:771-774, :780); every fingerprint match filed under an entry must be the same message --
-// false = a collision, the exact path redoes the target.
+// Output phase of fast_merge: gather the surviving messages from HBM, shift in the new bits, store coalesced
+// (:771-774, :780); the fingerprint match filed under an entry must be the same message -- false = a collision,
+// the exact path redoes the target.
 template <int LL, int P>
 __device__ __forceinline__ bool fast_output(const Geometry& g, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur, uint32_t k,
                                             uint32_t c, uint32_t cp, uint32_t own, uint32_t src, uint32_t sh, uint32_t nb,
                                             uint32_t np_dst, uint32_t np_src, unsigned long long asrc, unsigned long long rej0,
-                                            unsigned long long rej1, uint32_t lc, int l_begin, int l_end) {
+                                            uint32_t lc) {
   const uint32_t N = g.N, sBlk = g.sBlk, sCrf = mul24(sBlk, LL), pw = 2 * g.N;
   bool good = true;
   constexpr int GB = LL >= 4 ? 4 : LL;       // entries whose loads are in flight together (8: 86 VGPRs, slower)
 #pragma unroll
   for (int l0 = 0; l0 < LL; l0 += GB) {
-    if (l0 < l_begin || l0 >= l_end) continue;
     uint32_t m[GB][2 * P];
 #pragma unroll
     for (int u = 0; u < GB; ++u) {
@@ -863,21 +834,15 @@ __device__ __forceinline__ bool fast_output(const Geometry& g, const uint32_t* _
         const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu;
         push_bits<2 * P>(m[u], (a8 >> 3) == 0 ? 0u : sh, nb);      // (push_var here: 76 instead of 68 registers with four planes)
         store_msg<P>(cur + own + l * sBlk + pw, N, c, np_dst, m[u]);
-        const uint32_t r0 = (uint32_t)(rej0 >> (7 * l)) & 0x7Fu;
-        if (r0) {
+        const uint32_t rec = (uint32_t)(rej0 >> (7 * l)) & 0x7Fu;
+        if (rec & 0x40u) {
+          const uint32_t ri = (rec >> 3) & 7u, rj = rec & 7u;
+          const uint32_t rfrom = ri == 0 ? own + mul24(rj, sBlk) : src + mul24(list_crf(k, ri), sCrf) + mul24(rj, sBlk);
+          uint32_t qm[2 * P];
+          load_msg<P>(prev + rfrom + pw, N, ri == 0 ? c : cp, ri == 0 ? np_dst : np_src, qm);
+          push_bits<2 * P>(qm, ri == 0 ? 0u : sh, nb);
 #pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            const uint32_t rec = s2 ? (uint32_t)(rej1 >> (7 * l)) & 0x7Fu : r0;
-            if (rec & 0x40u) {
-              const uint32_t ri = (rec >> 3) & 7u, rj = rec & 7u;
-              const uint32_t rfrom = ri == 0 ? own + mul24(rj, sBlk) : src + mul24(list_crf(k, ri), sCrf) + mul24(rj, sBlk);
-              uint32_t qm[2 * P];
-              load_msg<P>(prev + rfrom + pw, N, ri == 0 ? c : cp, ri == 0 ? np_dst : np_src, qm);
-              push_bits<2 * P>(qm, ri == 0 ? 0u : sh, nb);
-#pragma unroll
-              for (int w = 0; w < 2 * P; ++w) good &= (qm[w] == m[u][w]);
-            }
-          }
+          for (int w = 0; w < 2 * P; ++w) good &= (qm[w] == m[u][w]);
         }
       }
     }
@@ -891,12 +856,11 @@ __device__ __forceinline__ bool fast_output(const Geometry& g, const uint32_t* _
 // target must be redone by the exact path.
 // The merge proper: decides the new list (scores and fingerprints are stored as it goes) and reports where every accepted
 // entry came from (asrc) and which fingerprint matches still have to be verified on the full message (rej0 / rej1).
-template <int LL, int NL, bool DRY = false>
+template <int LL, int NL>
 __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur,
                                                 const uint2* s_src, const float* s_post, uint32_t k, uint32_t c,
                                                 uint32_t sc, uint32_t own, uint32_t okmask, uint32_t fpc,
-                                                unsigned long long* o_asrc, unsigned long long* o_rej0, unsigned long long* o_rej1,
-                                                uint32_t* o_lc) {
+                                                unsigned long long* o_asrc, unsigned long long* o_rej0, uint32_t* o_lc) {
   const float NEG = -INFINITY;
   const uint32_t sBlk = g.sBlk;
   const uint32_t row = k >= 4 ? 4u : k;
@@ -933,22 +897,18 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
   }
 
   // Accepted entries.  ah: their fingerprints, NEWEST FIRST (a shift register: static register
-  // indices only).  asrc: 8 bits (list << 3 | index) per entry in acceptance order.  rej0/rej1:
-  // fingerprint matches waiting for verification, filed under the accepted entry they matched,
-  // 7 bits (valid, list, index) per entry and slot.  A message can sit in at most three lists
-  // (stay, flip X, flop X of the base it ends in), so two slots per entry do.
+  // indices only).  asrc: 8 bits (list << 3 | index) per entry in acceptance order.  rej0: the
+  // fingerprint match waiting for verification, filed under the accepted entry it matched,
+  // 7 bits (valid, list, index) per entry -- ONE per entry (see below).
   uint32_t ah[LL];
 #pragma unroll
   for (int l = 0; l < LL; ++l) ah[l] = 0;
-  unsigned long long asrc = 0, rej0 = 0, rej1 = 0;
+  unsigned long long asrc = 0, rej0 = 0;
   uint32_t ptr = 0, lc = 0;
 
   // The loop body is written branch-free (selects) except for the store of an accepted entry:
   // lanes that are done keep running harmless iterations until the wavefront's last lane exits.
   bool go = why == 0;
-#if LVA_ABLATE == 2
-  int abl_it = 0;
-#endif
   while (go) {                                                         // :764
     float M = h[0];
 #pragma unroll
@@ -1002,13 +962,9 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
     // target hardly ever share a message (instrumented oracle, scripts/merge_stats.py: 4-6 in 100 000 duplicate pops at
     // m = 6 / 8 / 11, clean and noisy), so an accepted entry has one match at most.  A second one -- a message in three
     // lists, or a fingerprint collision -- is reason 3: the exact path decides.
-    // (LVA_REJ_SLOTS=2 keeps a second slot per entry for eight-list merges, as until round 2.)
-    constexpr bool kSecond = LVA_REJ_SLOTS == 2 && NL > 2;
-    const bool full1 = kSecond ? reject && ((rej1 >> (s7 & 63u)) & 0x40u) : full0;
     rej0 |= (reject && !full0) ? rec << (s7 & 63u) : 0ull;
-    if constexpr (kSecond) rej1 |= (full0 && !full1) ? rec << (s7 & 63u) : 0ull;
     if (accept) {
-      if constexpr (!DRY) *reinterpret_cast<uint2*>(cur + own_c + mul24(lc, sBlk)) = make_uint2(f2u(M), ch);   // :780-783
+      *reinterpret_cast<uint2*>(cur + own_c + mul24(lc, sBlk)) = make_uint2(f2u(M), ch);   // :780-783
 #pragma unroll
       for (int a = LL - 1; a >= 1; --a) ah[a] = opq(ah[a - 1]);
       ah[0] = ch;
@@ -1019,21 +975,16 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
 #pragma unroll
     for (int i = 0; i < NL; ++i) h[i] = selv(eq[i], ns, h[i]);
     ptr += 1u << (4 * sel);
-    why = (alive && two) ? 1 : ((proceed && bad) ? 2 : ((full0 && full1) ? 3 : 0));
+    why = (alive && two) ? 1 : ((proceed && bad) ? 2 : (full0 ? 3 : 0));
     go = proceed && why == 0 && lc < (uint32_t)LL;
-#if LVA_ABLATE == 2
-    if (++abl_it >= 8) go = false;
-#endif
   }
   if (why) return why;
 
   // unused tail of the list (:799)
-  if constexpr (!DRY) {
 #pragma unroll
-    for (int l = 0; l < LL; ++l)
-      if ((uint32_t)l >= lc) *reinterpret_cast<uint2*>(cur + own_c + l * sBlk) = make_uint2(kNegInfBits, 0u);
-  }
-  *o_asrc = asrc; *o_rej0 = rej0; *o_rej1 = rej1; *o_lc = lc;
+  for (int l = 0; l < LL; ++l)
+    if ((uint32_t)l >= lc) *reinterpret_cast<uint2*>(cur + own_c + l * sBlk) = make_uint2(kNegInfBits, 0u);
+  *o_asrc = asrc; *o_rej0 = rej0; *o_lc = lc;
   return 0;
 }
 
@@ -1042,45 +993,11 @@ __device__ __forceinline__ int fast_merge(const Geometry& g, const uint32_t* __r
                                            const uint2* s_src, const float* s_post, uint32_t k, uint32_t c, uint32_t cp,
                                            uint32_t sc, uint32_t own, uint32_t src, uint32_t okmask, uint32_t sh,
                                            uint32_t nb, uint32_t fpc, uint32_t np_dst, uint32_t np_src) {
-  unsigned long long asrc, rej0, rej1;
+  unsigned long long asrc, rej0;
   uint32_t lc;
-  const int why = fast_merge_core<LL, NL>(g, prev, cur, s_src, s_post, k, c, sc, own, okmask, fpc, &asrc, &rej0, &rej1, &lc);
+  const int why = fast_merge_core<LL, NL>(g, prev, cur, s_src, s_post, k, c, sc, own, okmask, fpc, &asrc, &rej0, &lc);
   if (why) return why;
-  return fast_output<LL, P>(g, prev, cur, k, c, cp, own, src, sh, nb, np_dst, np_src, asrc, rej0, rej1, lc, 0, LL) ? 0 : 4;
-}
-
-// L == 1: plain add-compare-select, first maximum wins (:715-742).  No heap, no ties issue.
-template <int P, int NL>
-__device__ __forceinline__ void fast_acs(const Geometry& g, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur,
-                                         const uint2* s_src, const float* s_post, uint32_t k, uint32_t c, uint32_t cp,
-                                         uint32_t sc, uint32_t own, uint32_t src, uint32_t okmask, uint32_t sh,
-                                         uint32_t nb, uint32_t fpc, uint32_t np_dst, uint32_t np_src) {
-  const float NEG = -INFINITY;
-  const uint32_t sCrf = g.sBlk, pw = 2 * g.N;
-  const uint32_t row = k >= 4 ? 4u : k;
-  const uint32_t own_c = own + 2 * c;
-  float best = NEG; uint32_t bi = 0, bh = 0;
-  if (okmask & 1u) {
-    const uint2 v = *reinterpret_cast<const uint2*>(prev + own_c);
-    const float s = u2f(v.x) + s_post[row * 8 + k];
-    if (s > best) { best = s; bi = 0; bh = v.y; }
-  }
-#pragma unroll
-  for (int i = 1; i < NL; ++i) {
-    if ((okmask >> i) & 1u) {
-      const uint2 v = s_src[list_crf(k, i) * TS + sc];
-      const float s = u2f(v.x) + s_post[row * 8 + list_crf(k, i)];
-      if (s > best) { best = s; bi = i; bh = v.y ^ fpc; }
-    }
-  }
-  *reinterpret_cast<uint2*>(cur + own_c) = make_uint2(f2u(best), bh);
-  if (best != NEG) {
-    const uint32_t from = bi == 0 ? own : src + mul24(list_crf(k, bi), sCrf);
-    uint32_t m[2 * P];
-    load_msg<P>(prev + from + pw, g.N, bi == 0 ? c : cp, bi == 0 ? np_dst : np_src, m);
-    push_bits<2 * P>(m, bi == 0 ? 0u : sh, nb);
-    store_msg<P>(cur + own + pw, g.N, c, np_dst, m);
-  }
+  return fast_output<LL, P>(g, prev, cur, k, c, cp, own, src, sh, nb, np_dst, np_src, asrc, rej0, lc) ? 0 : 4;
 }
 
 // The butterfly: thread tid of the workgroup that owns source tile `tile` (TSx consecutive source
@@ -1265,14 +1182,8 @@ __global__ __launch_bounds__(8 * TS) void lva_step_fast(StepArgs args, Geometry 
   // ---- this thread's (role, target conv, base) ----
   TileTarget t;
   if (!tile_target<TS>(cd, g, ss, pos, tile, tid, &t)) return;
-  int why;
-  if (t.k < 4) {
-    if constexpr (LL == 1) { fast_acs<P, 8>(g, prev, cur, s_src, s_post, t.k, t.c, t.cp, t.sc, t.own, src, t.ok, t.sh, t.nb, t.fpc, t.np_dst, t.np_src); why = 0; }
-    else why = fast_merge<LL, P, 8>(g, prev, cur, s_src, s_post, t.k, t.c, t.cp, t.sc, t.own, src, t.ok, t.sh, t.nb, t.fpc, t.np_dst, t.np_src);
-  } else {
-    if constexpr (LL == 1) { fast_acs<P, 2>(g, prev, cur, s_src, s_post, t.k, t.c, t.cp, t.sc, t.own, src, t.ok, t.sh, t.nb, t.fpc, t.np_dst, t.np_src); why = 0; }
-    else why = fast_merge<LL, P, 2>(g, prev, cur, s_src, s_post, t.k, t.c, t.cp, t.sc, t.own, src, t.ok, t.sh, t.nb, t.fpc, t.np_dst, t.np_src);
-  }
+  const int why = t.k < 4 ? fast_merge<LL, P, 8>(g, prev, cur, s_src, s_post, t.k, t.c, t.cp, t.sc, t.own, src, t.ok, t.sh, t.nb, t.fpc, t.np_dst, t.np_src)
+                          : fast_merge<LL, P, 2>(g, prev, cur, s_src, s_post, t.k, t.c, t.cp, t.sc, t.own, src, t.ok, t.sh, t.nb, t.fpc, t.np_dst, t.np_src);
   const uint32_t k = t.k, c = t.c;
   if (why) {
     atomicAdd(&hdr->reason[why - 1], 1ull);
@@ -1372,12 +1283,7 @@ __device__ __forceinline__ void lazy_message(const LazyCtx& x, uint32_t i, uint3
 #pragma unroll
     for (int w = 0; w < 2 * P; ++w) mw[w] = 0;
   }
-#if LVA_PUSH_VAR
-  push_var<2 * P>(mw, s1 + s2, (n1 << s2) | (s2 ? x.nb_p : 0u));
-#else
-  push_bits<2 * P>(mw, s1, n1);
-  push_bits<2 * P>(mw, s2, x.nb_p);
-#endif
+  push_var<2 * P>(mw, s1 + s2, (n1 << s2) | (s2 ? x.nb_p : 0u));     // both moves in one funnel shift per word
 }
 
 __device__ __forceinline__ void lazy_ctx(const DevCode& cd, const Geometry& g, const SlotStep& ss, const uint32_t* slot_base, uint32_t pos,
@@ -1409,36 +1315,30 @@ __device__ __forceinline__ void lazy_ctx(const DevCode& cd, const Geometry& g, c
 template <int LL, int P, bool ANCHOR>
 __device__ __forceinline__ bool lazy_output(const Geometry& g, const LazyCtx& x, uint32_t* __restrict__ cur, uint32_t* __restrict__ mout,
                                             const uint8_t* s_bp, uint32_t sc, unsigned long long own_bp, unsigned long long asrc,
-                                            unsigned long long rej0, unsigned long long rej1, uint32_t lc) {
+                                            unsigned long long rej0, uint32_t lc) {
   bool good = true;
   // the candidate's own back-pointer byte: staged in LDS for source lists, prefetched for the stay list
   auto bp_of = [&](uint32_t i, uint32_t j) __attribute__((always_inline)) -> uint32_t {
     if (i == 0) return (uint32_t)(own_bp >> (8 * j)) & 0xFFu;
     return s_bp[(list_crf(x.k, i) * TS + sc) * LL + j];
   };
-  // every fingerprint match filed under entry l must be the same message as the entry's (mw)
+  // the fingerprint match filed under entry l must be the same message as the entry's (mw): anchor steps, where the
+  // entry's message is in registers anyway
   auto verify = [&](int l, const uint32_t (&mw)[2 * P]) __attribute__((always_inline)) {
-#if LVA_ABLATE == 3
-    return;
-#endif
+    const uint32_t rec = (uint32_t)(rej0 >> (7 * l)) & 0x7Fu;
+    if (rec & 0x40u) {
+      const uint32_t ri = (rec >> 3) & 7u, rj = rec & 7u;
+      uint32_t qm[2 * P];
+      lazy_message<P>(x, ri, rj, bp_of(ri, rj), qm);
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      const uint32_t rec = (uint32_t)((s2 ? rej1 : rej0) >> (7 * l)) & 0x7Fu;
-      if (rec & 0x40u) {
-        const uint32_t ri = (rec >> 3) & 7u, rj = rec & 7u;
-        uint32_t qm[2 * P];
-        lazy_message<P>(x, ri, rj, bp_of(ri, rj), qm);
-#pragma unroll
-        for (int w = 0; w < 2 * P; ++w) good &= (qm[w] == mw[w]);
-      }
+      for (int w = 0; w < 2 * P; ++w) good &= (qm[w] == mw[w]);
     }
   };
-  // Confirmation of the fingerprint matches as a loop over the entries that HAVE one (about one per target, rarely more than
-  // three): inside the unrolled entry loop each of the eight `if (match filed under entry l)` blocks runs for the whole
+  // Odd steps confirm their fingerprint matches in a loop over the entries that HAVE one (about one per target, rarely more
+  // than three): inside an unrolled entry loop each of the eight `if (match filed under entry l)` blocks runs for the whole
   // wavefront as soon as one lane has a match there -- always -- so a wavefront executed eight confirmations for one per lane.
-  constexpr bool kVerifyLoop = LVA_VERIFY_LOOP == 2 || (LVA_VERIFY_LOOP == 1 && !ANCHOR);
+  // (The same loop in the anchor instance, which has every entry's message in registers at some point anyway: -3 %.)
   auto verify_loop = [&]() __attribute__((always_inline)) {
-    static_assert(!kVerifyLoop || LVA_REJ_SLOTS == 1, "one record per entry");
     uint32_t todo = 0;
 #pragma unroll
     for (int l = 0; l < LL; ++l) todo |= ((uint32_t)(rej0 >> (7 * l + 6)) & 1u) << l;
@@ -1447,8 +1347,7 @@ __device__ __forceinline__ bool lazy_output(const Geometry& g, const LazyCtx& x,
       todo &= todo - 1u;
       const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0x3Fu, rec = (uint32_t)(rej0 >> (7 * l)) & 0x3Fu;
       uint32_t ma[2 * P], mb[2 * P];
-#if LVA_VERIFY_PAIRED
-      if constexpr (!ANCHOR) {
+      {
         // odd step: the pair is a stay entry (the target's own list, message where the last anchor step put it) and an entry of one
         // source list (two source lists: 5 in 100 000, the general path below).  Which is which differs per lane, where they live
         // does not: planes in use, message buffers and the move are uniform over the workgroup -- both messages are requested
@@ -1467,9 +1366,8 @@ __device__ __forceinline__ bool lazy_output(const Geometry& g, const LazyCtx& x,
           continue;
         }
       }
-#endif
-      lazy_message<P>(x, a8 >> 3, a8 & 7u, ANCHOR ? bp_of(a8 >> 3, a8 & 7u) : 0u, ma);
-      lazy_message<P>(x, rec >> 3, rec & 7u, ANCHOR ? bp_of(rec >> 3, rec & 7u) : 0u, mb);
+      lazy_message<P>(x, a8 >> 3, a8 & 7u, 0u, ma);
+      lazy_message<P>(x, rec >> 3, rec & 7u, 0u, mb);
 #pragma unroll
       for (int w = 0; w < 2 * P; ++w) good &= (ma[w] == mb[w]);
     }
@@ -1482,24 +1380,19 @@ __device__ __forceinline__ bool lazy_output(const Geometry& g, const LazyCtx& x,
       if ((uint32_t)l < lc) {
         const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu;
         packed |= (unsigned long long)(a8 | (lazy_mbuf(x, a8 >> 3) << 6)) << (8 * l);
-        if (!kVerifyLoop && ((uint32_t)(rej0 >> (7 * l)) & 0x40u)) {
-          uint32_t mw[2 * P];
-          lazy_message<P>(x, a8 >> 3, a8 & 7u, 0u, mw);
-          verify(l, mw);
-        }
       }
     }
     uint8_t* dst = reinterpret_cast<uint8_t*>(cur) + bp_byte_index(g, x.own, 0, x.c);
     if constexpr (LL == 8) *reinterpret_cast<unsigned long long*>(dst) = packed;
     else if constexpr (LL == 4) *reinterpret_cast<uint32_t*>(dst) = (uint32_t)packed;
     else *reinterpret_cast<uint16_t*>(dst) = (uint16_t)packed;
-    if constexpr (kVerifyLoop) verify_loop();
+    verify_loop();
     return good;
   }
-  // ---- anchor step: two hops to the stored message, both moves applied, stored coalesced; LVA_LAZY_GB entries in flight ----
+  // ---- anchor step: two hops to the stored message, both moves applied, stored coalesced; kLazyInFlight entries in flight ----
   // (four message planes: one entry in flight -- 8 more message registers would cost the anchor instance a wavefront per SIMD;
   //  measured at m=14: 4.91 against 4.69 reads/s)
-  constexpr int GBW = P >= 4 ? 1 : LVA_LAZY_GB;
+  constexpr int GBW = P >= 4 ? 1 : kLazyInFlight;
   constexpr int GB = LL >= GBW ? GBW : LL;
 #pragma unroll
   for (int l0 = 0; l0 < LL; l0 += GB) {
@@ -1522,18 +1415,12 @@ __device__ __forceinline__ bool lazy_output(const Geometry& g, const LazyCtx& x,
     for (int u = 0; u < GB; ++u) {
       const int l = l0 + u;
       if ((uint32_t)l < lc) {
-#if LVA_PUSH_VAR
         push_var<2 * P>(m[u], (mv[u] & 3u) + (mv[u] >> 4), (((mv[u] >> 2) & 3u) << (mv[u] >> 4)) | ((mv[u] >> 4) ? x.nb_p : 0u));
-#else
-        push_bits<2 * P>(m[u], mv[u] & 3u, (mv[u] >> 2) & 3u);
-        push_bits<2 * P>(m[u], mv[u] >> 4, x.nb_p);
-#endif
         store_msg<P>(mout + x.own + l * x.sBlk + x.pw, x.N, x.c, x.np_p, m[u]);
-        if (!kVerifyLoop && ((uint32_t)(rej0 >> (7 * l)) & 0x40u)) verify(l, m[u]);
+        if ((uint32_t)(rej0 >> (7 * l)) & 0x40u) verify(l, m[u]);
       }
     }
   }
-  if constexpr (kVerifyLoop) verify_loop();
   return good;
 }
 
@@ -1543,7 +1430,7 @@ __device__ __forceinline__ bool lazy_output(const Geometry& g, const LazyCtx& x,
 // ANCHOR = false those at an odd step (workgroups of the other kind leave at once) -- the odd-step path keeps the
 // merge's small register footprint (no message in flight), the anchor path is the only one that pays for two hops.
 template <int LL, int P, bool ANCHOR>
-__global__ __launch_bounds__(8 * TS, ANCHOR ? LVA_LAZY_ANCHOR_MINWAVES : LVA_LAZY_ODD_MINWAVES) void lva_step_lazy(StepArgs args, Geometry g, const DevCode* __restrict__ codes,
+__global__ __launch_bounds__(8 * TS, kLazyMinWaves) void lva_step_lazy(StepArgs args, Geometry g, const DevCode* __restrict__ codes,
                                                      uint32_t* __restrict__ trellis, WorkHdr* __restrict__ hdr,
                                                      uint32_t* __restrict__ items) {
   __shared__ uint2 s_src[8 * LL * TS];
@@ -1609,29 +1496,14 @@ __global__ __launch_bounds__(8 * TS, ANCHOR ? LVA_LAZY_ANCHOR_MINWAVES : LVA_LAZ
     else if constexpr (LL == 4) own_bp = *reinterpret_cast<const uint32_t*>(bpp);
     else own_bp = *reinterpret_cast<const uint16_t*>(bpp);
   }
-  unsigned long long asrc = 0, rej0 = 0, rej1 = 0;
+  unsigned long long asrc = 0, rej0 = 0;
   uint32_t lc = 0;
-#if LVA_ABLATE == 5
-  if (tid < 4096) return;
-#endif
-#if LVA_ABLATE == 6       // the merge once more without its stores, result kept alive through an impossible condition
-  {
-    unsigned long long a2 = 0, r2 = 0, r3 = 0; uint32_t lc2 = 0;
-    const int w2 = t.k < 4 ? fast_merge_core<LL, 8, true>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &a2, &r2, &r3, &lc2)
-                           : fast_merge_core<LL, 2, true>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &a2, &r2, &r3, &lc2);
-    if (w2 == 77 || lc2 + (uint32_t)a2 + (uint32_t)r2 == 0xFEEDBEEFu) hdr->pad = 1u;
-  }
-#endif
-  int why = t.k < 4 ? fast_merge_core<LL, 8>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &rej1, &lc)
-                    : fast_merge_core<LL, 2>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &rej1, &lc);
+  int why = t.k < 4 ? fast_merge_core<LL, 8>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &lc)
+                    : fast_merge_core<LL, 2>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &lc);
   if (!why) {
     LazyCtx x;
     lazy_ctx(cd, g, ss, slot_base, pos, t.c, t.cp, t.k, t.own, &x, ANCHOR ? (int)t.pk1 : 0);
-    if (!lazy_output<LL, P, ANCHOR>(g, x, cur, mout, s_bp, t.sc, own_bp, asrc, rej0, rej1, lc)) why = 4;
-#if LVA_ABLATE == 7       // the output phase once more (the same stores again: idempotent)
-    asm volatile("" ::: "memory");
-    if (!lazy_output<LL, P, ANCHOR>(g, x, cur, mout, s_bp, t.sc, own_bp, asrc, rej0, rej1, lc)) why = 4;
-#endif
+    if (!lazy_output<LL, P, ANCHOR>(g, x, cur, mout, s_bp, t.sc, own_bp, asrc, rej0, lc)) why = 4;
   }
   if (why) {
     atomicAdd(&hdr->reason[why - 1], 1ull);
@@ -1879,16 +1751,8 @@ __global__ __launch_bounds__(4 * TS) void lva_step_acs(StepArgs args, Geometry g
 // ---------------------------------------------------------------------------------------
 namespace {
 
-#ifndef LVA_TSB
-#define LVA_TSB 32
-#endif
-#ifndef LVA_BIG_SHSTORE
-#define LVA_BIG_SHSTORE 0      // 1: accepted (score, fingerprint) pairs stored inside the merge loop: 6.94 instead of 6.14 ms per launch
-#endif
-#ifndef LVA_BIG_GB
-#define LVA_BIG_GB 6
-#endif
-constexpr uint32_t TSB = LVA_TSB;   // source conv states per workgroup tile (workgroup = 8*TSB threads)
+constexpr uint32_t TSB = 32;        // source conv states per workgroup tile (workgroup = 8*TSB threads)
+constexpr uint32_t kBigInFlight = 6;   // output phase at L > 32: entries whose loads are in flight together
 
 template <int LL, int P, int NL>
 __device__ __forceinline__ int big_merge(const Geometry& g, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur,
@@ -1961,12 +1825,6 @@ __device__ __forceinline__ int big_merge(const Geometry& g, const uint32_t* __re
     const unsigned long long hi9 = (unsigned long long)(sel >> 2);
     if (accept) {
       s_acc[lc * NT] = (uint8_t)from9;
-#if LVA_BIG_SHSTORE
-      // (score, fingerprint) of the accepted entry goes out now: the lanes of a wavefront accept at nearly the same
-      // list index, so the 8-byte pieces of a row meet in L2 -- and the output phase need not read the source
-      // entry again (a 64-lane gather of 8 bytes per 64-byte line)
-      *reinterpret_cast<uint2*>(cur + own_c + mul24(lc, sBlk)) = make_uint2(f2u(M), ch);
-#endif
     }
     acc_hi |= accept ? hi9 << lc : 0ull;
     const uint32_t ra = lc - 1u - (uint32_t)q;                 // the entry it matched (only meaningful when reject)
@@ -2003,7 +1861,7 @@ __device__ __forceinline__ int big_merge(const Geometry& g, const uint32_t* __re
   // outputs, entry l of the whole wavefront at a time (:771-774, :780-783, :799).  Every fingerprint
   // match filed under an entry must be the same message (else: collision, the exact path decides).
   bool good = true;
-  constexpr uint32_t GB = LL >= 64 ? LVA_BIG_GB : 4;       // entries whose loads are in flight together (VGPRs: the fingerprints are dead by now)
+  constexpr uint32_t GB = LL >= 64 ? kBigInFlight : 4;       // entries whose loads are in flight together (VGPRs: the fingerprints are dead by now)
   for (uint32_t l0 = 0; l0 < L; l0 += GB) {
     uint32_t m[GB][2 * P], q0[GB][2 * P]; uint2 sh2[GB]; uint32_t iu[GB], ir[GB];
 #pragma unroll
@@ -2013,9 +1871,7 @@ __device__ __forceinline__ int big_merge(const Geometry& g, const uint32_t* __re
       if (l < lc) {
         const uint32_t f = locate((uint32_t)s_acc[l * NT] | ((uint32_t)(acc_hi >> l) & 1u) << 8, &iu[u]);
         const uint32_t cv = iu[u] == 0 ? t.c : t.cp;
-#if !LVA_BIG_SHSTORE
         sh2[u] = *reinterpret_cast<const uint2*>(prev + f + 2 * cv);
-#endif
         load_msg<P>(prev + f + pw, N, cv, iu[u] == 0 ? t.np_dst : t.np_src, m[u]);
         if ((rv0 >> l) & 1ull) {          // the first match filed under this entry: its load travels with the others
           const uint32_t fr = locate((uint32_t)s_rej0[l * NT] | ((uint32_t)(rh0 >> l) & 1u) << 8, &ir[u]);
@@ -2027,15 +1883,9 @@ __device__ __forceinline__ int big_merge(const Geometry& g, const uint32_t* __re
     for (uint32_t u = 0; u < GB; ++u) {
       const uint32_t l = l0 + u;
       if (l < lc) {
-#if !LVA_BIG_SHSTORE
         const float sc = u2f(sh2[u].x) + ladd(iu[u]);
         *reinterpret_cast<uint2*>(cur + own_c + mul24(l, sBlk)) = make_uint2(f2u(sc), iu[u] ? sh2[u].y ^ t.fpc : sh2[u].y);
-#endif
-#if LVA_PUSH_VAR
         push_var<2 * P>(m[u], iu[u] == 0 ? 0u : t.sh, iu[u] == 0 ? 0u : t.nb);
-#else
-        push_bits<2 * P>(m[u], iu[u] == 0 ? 0u : t.sh, t.nb);
-#endif
         store_msg<P>(cur + t.own + mul24(l, sBlk) + pw, N, t.c, t.np_dst, m[u]);
         if ((rv0 >> l) & 1ull) {
           push_bits<2 * P>(q0[u], ir[u] == 0 ? 0u : t.sh, t.nb);
@@ -2302,7 +2152,7 @@ int launch_step_fast(const StepArgs& a, const Geometry& g, const DevCode* codes,
     if (e) return e;
     if (ev_mid && (e = (int)hipEventRecord((hipEvent_t)ev_mid, st))) return e;
     // one target per wavefront and pass: the pass is a chain of dependent round trips, so more (mostly idle) wavefronts, not fewer
-    constexpr uint32_t kFixGrid = LVA_FIXUP_LAZY_GRID;
+    constexpr uint32_t kFixGrid = kFixupLazyGrid;
     switch (g.P) {
       case 1: hipLaunchKernelGGL((lva_step_fixup_lazy<1>), dim3(kFixGrid), dim3(256), 0, st, a, g, codes, trellis, hdr, items); break;
       case 2: hipLaunchKernelGGL((lva_step_fixup_lazy<2>), dim3(kFixGrid), dim3(256), 0, st, a, g, codes, trellis, hdr, items); break;
@@ -2312,7 +2162,6 @@ int launch_step_fast(const StepArgs& a, const Geometry& g, const DevCode* codes,
     return (int)hipGetLastError();
   }
   switch (g.L) {
-#if LVA_ACS_KERNEL
     case 1: {
       dim3 grid(g.N / TS, a.band_max, a.nslots), block(4 * TS);
       switch (g.P) {
@@ -2325,9 +2174,6 @@ int launch_step_fast(const StepArgs& a, const Geometry& g, const DevCode* codes,
       e = (int)hipGetLastError();
       break;
     }
-#else
-    case 1: e = launch_fast_p<1>(a, g, codes, trellis, hdr, items, st); break;
-#endif
     case 2: e = launch_fast_p<2>(a, g, codes, trellis, hdr, items, st); break;
     case 4: e = launch_fast_p<4>(a, g, codes, trellis, hdr, items, st); break;
     case 8: e = launch_fast_p<8>(a, g, codes, trellis, hdr, items, st); break;

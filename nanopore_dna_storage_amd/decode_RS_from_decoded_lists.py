@@ -45,11 +45,8 @@ def main(argv=None, out=sys.stdout):
             if os.path.isfile(list_file):
                 with open(list_file) as f:
                     lists.append([ln.rstrip("\n") for ln in f.readlines()][:a.list_size])
-        try:
-            data, _ = rs_code.decode_from_lists(lists, a.bytes_per_oligo, num_oligos_RS, num_oligos, pad=a.pad, device=a.device)
-            ok = data[:data_file_size] == original
-        except IndexError:          # no read passed the filter: the reference dies in MainDecoder here
-            ok = False
+        data, passed = rs_code.decode_from_lists(lists, a.bytes_per_oligo, num_oligos_RS, num_oligos, pad=a.pad, device=a.device)
+        ok = passed > 0 and data[:data_file_size] == original     # no read passed the filter: the reference dies in MainDecoder
         num_successes += int(ok)
         print("Success" if ok else "Failure", file=out)
     print("NUM_TRIALS", a.num_trials, file=out)

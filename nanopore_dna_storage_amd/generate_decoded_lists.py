@@ -110,11 +110,28 @@ def decode_rows(args, rows, dec):
 def write_list_file(path, msgs):
     """one decoded list, written to a temporary name and moved into place: a run killed in the middle never leaves
     a truncated OUT_PREFIX_i that --resume would take for a finished read"""
-    tmp = path + ".tmp%d" % os.getpid()
+    d, base = os.path.split(path)
+    tmp = os.path.join(d, TMP_PREFIX + base + "-%d" % os.getpid())     # never matches OUT_PREFIX_<i> (list consumers take every list_*)
     with open(tmp, "w") as f:
         for row in msgs:
             f.write("".join("1" if b else "0" for b in row) + "\n")
+        f.flush()
+        os.fsync(f.fileno())                     # the rename must not become durable before the data
     os.replace(tmp, path)
+
+
+TMP_PREFIX = ".tmp-"
+
+
+def remove_stale_temp_files(out_prefix):
+    """temporary list files a killed run left behind (start-up of every run)"""
+    d, base = os.path.split(out_prefix)
+    for name in os.listdir(d or "."):
+        if name.startswith(TMP_PREFIX + base + "_"):
+            try:
+                os.remove(os.path.join(d or ".", name))
+            except OSError:
+                pass
 
 
 def run(args, out=sys.stdout, dist=None, device=None, coll_dev=None):
@@ -123,6 +140,8 @@ def run(args, out=sys.stdout, dist=None, device=None, coll_dev=None):
     after a crash).  Per chunk: strided shards over the ranks, decode, gather on rank 0, rank 0 writes the files."""
     rows = read_manifest(args)
     n = len(rows)
+    if dist is None or dist.get_rank() == 0:
+        remove_stale_temp_files(args.out_prefix)
     done = [args.resume and os.path.exists(args.out_prefix + "_" + str(i)) for i in range(n)]
     work = [i for i in range(n) if not done[i]]
     world = dist.get_world_size() if dist is not None else 1

@@ -61,9 +61,9 @@ def MainDecoder(listofcorruptedreads, redundancy, totalnumreads, device=0, retur
     reads = [b"".rjust(2 * spr, b"0")] * totalnumreads                 # dummy reads (:242-243)
     present = np.zeros(totalnumreads, bool)
     for idx, payload in listofcorruptedreads:
-        reads[idx] = payload
         if not 0 <= idx < totalnumreads or present[idx]:
             raise ValueError("list.remove(x): x not in list")          # erasure_loc_list.remove (:247)
+        reads[idx] = payload
         present[idx] = True
     cols = _columns(reads)
     erasures = np.ascontiguousarray(np.nonzero(~present)[0], dtype=np.int32)
@@ -105,5 +105,7 @@ def decode_from_lists(lists, bytes_per_oligo, num_oligos_RS, num_oligos, pad=Fal
         index, payload, _ = helper.decode_list_CRC_index(lst if list_size is None else lst[:list_size], bytes_per_oligo, num_oligos, pad)
         if index is not None:
             decoded.append((index, payload))
+    if not decoded:                 # nothing to decode from (the reference's MainDecoder raises IndexError on an empty list)
+        return b"", 0
     rs_out = MainDecoder(consensus(decoded), num_oligos_RS, num_oligos, device=device)
     return b"".join(rs_out), len(decoded)

@@ -70,6 +70,16 @@ CASES = [
     ("m11_r5_L64_rc", 11, 5, 180, 64, 20, True, 4.0, 309, {}),
     ("m8_r3_L64", 8, 3, 164, 64, 20, False, 3.0, 206, {}),          # supplement 5.2: list size 64 at m=8
     ("m8_r3_L64_rc", 8, 3, 164, 64, 20, True, 3.0, 207, {}),
+    # round 4: non-finite posteriors (NaN, +inf: whatever the reference does with them), messages wider than 192 bits
+    # (four message planes), a list longer than 64 (the thread-per-target kernel)
+    ("m6_r1_L4_nan", 6, 1, 60, 4, 20, False, 4.0, 601, {"nan": 0.01}),
+    ("m6_r1_L4_posinf_rc", 6, 1, 60, 4, 20, True, 4.0, 602, {"posinf": 0.01}),
+    ("m6_r1_L8_nan_posinf", 6, 1, 60, 8, 20, False, 3.0, 603, {"nan": 0.005, "posinf": 0.005}),
+    ("m6_r1_L1_nan_posinf", 6, 1, 60, 1, 20, False, 4.0, 604, {"nan": 0.01, "posinf": 0.01}),
+    ("m6_r1_L16_nan", 6, 1, 60, 16, 20, False, 3.0, 605, {"nan": 0.01}),
+    ("m6_r1_L8_wide", 6, 1, 200, 8, 20, False, 3.0, 606, {}),
+    ("m6_r5_L4_wide_ties_rc", 6, 5, 190, 4, 20, True, 3.0, 607, {"quantum": 0.5}),
+    ("m6_r1_L100", 6, 1, 60, 100, 20, False, 3.0, 608, {}),
 ]
 
 # decode invocations the reference refuses or aborts on: (name, args..., truncate post to n blocks)
@@ -100,8 +110,15 @@ def main():
             continue
         sync = {k: extra[k] for k in ("sync_marker", "sync_period") if k in extra}
         gen = {k: extra[k] for k in ("quantum", "sub", "dele", "ins") if k in extra}
+        bad = {k: extra[k] for k in ("nan", "posinf") if k in extra}
         rd = synth.make_read(m, r, msg_len, seed, rc=rc, margin=margin, **gen)
         post = rd["post"]
+        if "nan" in extra or "posinf" in extra:          # a fixed share of the posteriors replaced (seeded by the case)
+            u = np.random.default_rng(seed).random(post.shape)
+            post = post.copy()
+            fn, fp = extra.get("nan", 0.0), extra.get("posinf", 0.0)
+            post[u < fn] = np.nan
+            post[(u >= fn) & (u < fn + fp)] = np.inf
         if "truncate" in extra:
             post = post[:extra["truncate"]]
         post.tofile(os.path.join(HERE, name + ".post"))
@@ -116,7 +133,7 @@ def main():
                               margin=margin, seed=seed, nblk=int(post.shape[0]), exit_code=code,
                               n_lines=len(lines), message=truth,
                               top_correct=bool(lines[:1] == [truth]), list_correct=bool(truth in lines),
-                              ref_seconds=round(dt, 2), ref_threads=a.threads, **sync, **gen)
+                              ref_seconds=round(dt, 2), ref_threads=a.threads, **sync, **gen, **bad)
         print("%-22s nblk=%4d exit=%d lines=%d top=%s list=%s %.1fs" % (
             name, post.shape[0], code, len(lines), lines[:1] == [truth], truth in lines, dt), flush=True)
         json.dump(manifest, open(man_path, "w"), indent=1, sort_keys=True)
