@@ -439,6 +439,7 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
     return LVA_OK;
   };
   for (;;) {
+    size_t waiting = 0;              // slots whose read starts with the next launch (lazy mode's phase alignment)
     // (re)fill idle slots: the read's descriptor and initial scores (:657-663) go in stream order
     for (size_t s = 0; s < slot.size(); ++s) {
       if (slot[s].read >= 0 || next >= order.size()) continue;
@@ -447,8 +448,12 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
       sd.post = post_dev + (size_t)beg[r] * 40;
       sd.band = d->d_band + band_at[(size_t)r];
       sd.nblk = (uint32_t)len[r]; sd.orient = rc_flags && rc_flags[r] ? 1u : 0u;
-      sd.start = d->launch_no; sd.pad = 0;
-      slot[s].read = r; slot[s].end = d->launch_no + sd.nblk;
+      // Lazy mode: every read starts on an EVEN launch (a read that arrives on an odd one idles for one launch: 1 in ~500),
+      // so all slots are at an even time step on even launches and at an odd one on odd launches -- a launch then runs ONE
+      // instance of lva_step_lazy over a grid without workgroups of the wrong kind (launch_step_fast, phase_aligned)
+      sd.start = d->launch_no + (d->kernel == 4 ? (d->launch_no & 1u) : 0u); sd.pad = 0;
+      slot[s].read = r; slot[s].end = sd.start + sd.nblk;
+      if (sd.start != d->launch_no) ++waiting;
       const int e = launch_init_slot(g, d->d_codes, d->d_trellis, (uint32_t)s, sd, d->d_slots, d->stream);
       if (e) { g_hip_error = hipGetErrorString((hipError_t)e); return LVA_ERR_HIP; }
       d->prof.algorithmic_bytes += d->code[sd.orient].algorithmic_bytes(sd.nblk, L, d->max_dev);
@@ -458,6 +463,7 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
     StepArgs a;
     a.slots = d->d_slots; a.steps = d->d_steps; a.nslots = (uint32_t)slot.size(); a.band_max = band_max;
     a.launch_no = d->launch_no; a.step_parity = d->launch_no & 1u;
+    a.phase_aligned = d->kernel == 4 ? 1u : 0u;
     {
       const int e = launch_prepare_step(a, d->d_steps, d->stream);
       if (e) { g_hip_error = hipGetErrorString((hipError_t)e); return LVA_ERR_HIP; }
@@ -485,7 +491,7 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
     }
     ++d->launch_no;
     d->prof.step_launches += 1;
-    d->prof.read_steps += active;
+    d->prof.read_steps += active - waiting;
     // retire finished reads
     for (size_t s = 0; s < slot.size(); ++s) {
       if (slot[s].read < 0 || slot[s].end != d->launch_no) continue;

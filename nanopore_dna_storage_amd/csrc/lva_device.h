@@ -92,6 +92,9 @@ struct StepArgs {
   uint32_t band_max;             // positions per band at most (grid y)
   uint32_t step_parity;          // launch_no & 1: selects the work-list counter
   uint32_t launch_no;
+  uint32_t phase_aligned;        // lazy mode: every slot's time step has the parity of launch_no (the host starts reads on even
+                                 // launches only), so only the lva_step_lazy instance of that parity is launched
+  uint32_t pad;
 };
 
 struct Geometry {                // strides in 32-bit words

@@ -2138,8 +2138,11 @@ int launch_step_fast(const StepArgs& a, const Geometry& g, const DevCode* codes,
   }
   if (g.lazy) {
     dim3 grid(g.N / TS, a.band_max, a.nslots), block(8 * TS);
-#define LVA_LAZY_CASE(LLv, Pv) { hipLaunchKernelGGL((lva_step_lazy<LLv, Pv, true>), grid, block, 0, st, a, g, codes, trellis, hdr, items); \
-                                 hipLaunchKernelGGL((lva_step_lazy<LLv, Pv, false>), grid, block, 0, st, a, g, codes, trellis, hdr, items); }
+    // phase-aligned slots (the host starts every read on an even launch): all slots are at an even time step on even launches
+    // and at an odd one on odd launches -- one instance per launch, no workgroups of the wrong kind
+    const bool run_anchor = !a.phase_aligned || !(a.launch_no & 1u), run_odd = !a.phase_aligned || (a.launch_no & 1u);
+#define LVA_LAZY_CASE(LLv, Pv) { if (run_anchor) hipLaunchKernelGGL((lva_step_lazy<LLv, Pv, true>), grid, block, 0, st, a, g, codes, trellis, hdr, items); \
+                                 if (run_odd) hipLaunchKernelGGL((lva_step_lazy<LLv, Pv, false>), grid, block, 0, st, a, g, codes, trellis, hdr, items); }
 #define LVA_LAZY_L(LLv) switch (g.P) { case 1: LVA_LAZY_CASE(LLv, 1); break; case 2: LVA_LAZY_CASE(LLv, 2); break; \
                                       case 3: LVA_LAZY_CASE(LLv, 3); break; case 4: LVA_LAZY_CASE(LLv, 4); break; default: return (int)hipErrorInvalidValue; }
     switch (g.L) {
