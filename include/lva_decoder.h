@@ -90,6 +90,8 @@ typedef struct lva_profile {
   uint64_t timed_launches;    /* launches in those sums */
   double h2d_ms;              /* lva_decode_batch: HIP-event time of the host->device copy of the posteriors */
   uint64_t h2d_bytes;
+  uint64_t overflow_steps;    /* launches whose work list of undecided targets overflowed: the exact path redid the whole
+                                 step (tie-dense posteriors; correct, but a large slow-down the caller can now see) */
 } lva_profile;
 
 const char *lva_version(void);

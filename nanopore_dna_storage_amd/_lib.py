@@ -62,7 +62,8 @@ class Profile(ctypes.Structure):
                 ("fixup_reason", ctypes.c_uint64 * 4),
                 ("slots", ctypes.c_int32), ("kernel", ctypes.c_int32),
                 ("dominant_kernel_ms", ctypes.c_double), ("step_pair_ms", ctypes.c_double),
-                ("timed_launches", ctypes.c_uint64), ("h2d_ms", ctypes.c_double), ("h2d_bytes", ctypes.c_uint64)]
+                ("timed_launches", ctypes.c_uint64), ("h2d_ms", ctypes.c_double), ("h2d_bytes", ctypes.c_uint64),
+                ("overflow_steps", ctypes.c_uint64)]
 
 
 class PayloadPos(ctypes.Structure):

@@ -424,7 +424,7 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
   std::vector<Slot> slot((size_t)std::min<size_t>((size_t)d->slots, std::max<size_t>(order.size(), 1)));
   size_t next = 0;
   gathered.assign((size_t)n, 0);
-  d->prof.step_launches = 0; d->prof.read_steps = 0; d->prof.algorithmic_bytes = 0; d->prof.fixup_states = 0;
+  d->prof.step_launches = 0; d->prof.read_steps = 0; d->prof.algorithmic_bytes = 0; d->prof.fixup_states = 0; d->prof.overflow_steps = 0;
   d->prof.dominant_kernel_ms = 0; d->prof.step_pair_ms = 0; d->prof.timed_launches = 0;
   const uint32_t band_max = std::min<uint32_t>(npos, 2 * d->max_dev);
   bool first_step = true;
@@ -516,6 +516,7 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
   HIP_TRY(hipStreamSynchronize(d->stream));
   drain.armed = false;
   d->prof.fixup_states = h1.total;
+  d->prof.overflow_steps = h1.overflow_steps;
   for (int i = 0; i < 4; ++i) d->prof.fixup_reason[i] = h1.reason[i];
   float ms = 0;
   if (!first_step) { HIP_TRY(hipEventElapsedTime(&ms, d->ev_step0, d->ev_step1)); }

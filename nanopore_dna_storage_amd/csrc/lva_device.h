@@ -121,9 +121,10 @@ inline Geometry make_geometry(uint32_t N, uint32_t L, uint32_t msg_bits, uint32_
 struct WorkHdr {
   uint32_t count[2];             // per step parity
   uint32_t overflow[2];          // list full: the exact kernel redoes the whole step
-  unsigned long long total;      // states redone since the last reset (profile)
+  unsigned long long total;      // queued states redone since the last reset (profile)
   uint32_t cap;
-  uint32_t pad;
+  uint32_t overflow_steps;       // launches whose work list overflowed: the fix-up pass redid the WHOLE step on its exact path
+                                 // (a performance cliff on tie-dense input that callers should be able to see)
   unsigned long long reason[4];  // why: 0 tie on top, 1 non-finite arithmetic, 2 too many fingerprint matches, 3 fingerprint collision
 };
 

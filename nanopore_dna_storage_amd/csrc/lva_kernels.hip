@@ -564,7 +564,9 @@ __global__ __launch_bounds__(256) void lva_step_fixup(StepArgs args, Geometry g,
   const uint32_t n = hdr->count[par] < hdr->cap ? hdr->count[par] : hdr->cap;
   const bool all = hdr->overflow[par] != 0;
   if (n == 0 && !all) return;
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&hdr->total, (unsigned long long)(all ? 0xFFFFFFFFu : n));
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (all) atomicAdd(&hdr->overflow_steps, 1u); else atomicAdd(&hdr->total, (unsigned long long)n);
+  }
   Target tg;
   if (all) {   // work list overflowed: redo the whole step, one thread per target
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
@@ -767,7 +769,9 @@ __global__ __launch_bounds__(256, 8) void lva_step_fixup_wave(StepArgs args, Geo
   const uint32_t n = hdr->count[par] < hdr->cap ? hdr->count[par] : hdr->cap;
   const bool all = hdr->overflow[par] != 0;
   if (n == 0 && !all) return;
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&hdr->total, (unsigned long long)(all ? 0xFFFFFFFFu : n));
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (all) atomicAdd(&hdr->overflow_steps, 1u); else atomicAdd(&hdr->total, (unsigned long long)n);
+  }
   // work list overflowed: the whole step once more on this exact path (every target of every slot; no other code in this
   // kernel -- a call of the thread-per-target routine would cost it 114 registers and its candidate registers a place in scratch memory)
   const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u, nwaves = gridDim.x * 4;
@@ -1526,7 +1530,9 @@ __global__ __launch_bounds__(256) void lva_step_fixup_lazy(StepArgs args, Geomet
   // exact path reads only the previous step's rows and message rows no step is writing, so redoing a target is idempotent)
   const bool all = hdr->overflow[par] != 0;
   if (n == 0 && !all) return;
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&hdr->total, (unsigned long long)(all ? 0xFFFFFFFFu : n));
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (all) atomicAdd(&hdr->overflow_steps, 1u); else atomicAdd(&hdr->total, (unsigned long long)n);
+  }
   const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u, nwaves = gridDim.x * 4;
   const uint32_t mm = codes[0].m;
   const uint64_t per_slot = (uint64_t)args.band_max * g.N * 8;

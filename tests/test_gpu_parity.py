@@ -134,7 +134,7 @@ def test_tie_dense_batch_through_default_slots(oracle):
         with pkg.Decoder(m["mem_conv"], m["rate"], m["msg_len"], list_size=m["list_size"], max_deviation=m["max_deviation"]) as dec:
             assert dec.profile()["kernel"] == 4 and dec.profile()["slots"] == 1024
             got = dec.decode([post] * 300, rc=[m["rc"]] * 300)
-            assert dec.profile()["fixup_states"] > 0
+            assert dec.profile()["overflow_steps"] > 0        # whole steps were redone on the exact path, and the caller can see it
         for g in got:
             assert not isinstance(g, int), "decode error %r" % (g,)
             assert as_strings(g[0]) == lines
@@ -199,7 +199,7 @@ def test_big_list_kernel_three_planes_overflow_and_turnover(oracle, monkeypatch,
     monkeypatch.setenv("LVA_WORK_CAP", "4")
     _compare(oracle, 6, 1, 150, L, md, reads, kernel=2, max_slots=2)
     monkeypatch.delenv("LVA_WORK_CAP")
-    reads = [synth.make_read(6, 1, 150, 7700 + i, rc=bool(i % 3 == 0), margin=2.5 + (i % 3)) for i in range(40)]
+    reads = [synth.make_read(6, 1, 150, 7700 + i, rc=bool(i % 3 == 0), margin=2.5 + (i % 3)) for i in range(14 if md > 10 else 40)]
     assert len({x["post"].shape[0] & 1 for x in reads}) == 2
     _compare(oracle, 6, 1, 150, L, md, reads, kernel=0, max_slots=3)
 
