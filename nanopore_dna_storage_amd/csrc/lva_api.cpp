@@ -227,7 +227,11 @@ int lva_decoder_create(const lva_config* cfg, lva_decoder** out) {
   if (cfg->kernel == 4 && !lazy_ok) { delete d; return LVA_ERR_UNSUPPORTED; }
   const bool lazy = cfg->kernel == 4 || (cfg->kernel == 0 && lazy_ok);
   const uint64_t ring = std::min<uint64_t>(c.npos, 2ull * d->max_dev + (lazy ? 2 : 1));
-  d->g = make_geometry(c.nconv, cfg->list_size, c.msg_bits(), (uint32_t)std::max<uint64_t>(ring, 1), lazy ? 1u : 0u);
+  // the big-list kernel (kernel mode 2 at list sizes without a small-list instance) keeps its lists in the record layout
+  // where the message has three planes and L is a multiple of 4 (Geometry::rec)
+  const bool small = cfg->list_size == 1 || cfg->list_size == 2 || cfg->list_size == 4 || cfg->list_size == 8;
+  const bool big = !lazy && !small && cfg->list_size <= 64 && (cfg->kernel == 0 || cfg->kernel == 2) && c.nconv >= 64;
+  d->g = make_geometry(c.nconv, cfg->list_size, c.msg_bits(), (uint32_t)std::max<uint64_t>(ring, 1), lazy ? 1u : 0u, big ? 1u : 0u);
   if (d->g.sPar >= ((uint64_t)1 << 32)) { delete d; return LVA_ERR_TOO_MANY_STATES; }
 
   int ndev = 0;

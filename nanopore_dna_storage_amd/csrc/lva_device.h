@@ -101,14 +101,19 @@ struct Geometry {                // strides in 32-bit words
   uint32_t N, L, W, F, R, P;
   uint32_t sBlk;                 // one (ring, crf, list entry) block = N*F
   uint32_t lazy;                 // kernel mode 4: messages are materialised every second time step (lva_kernels.hip, "lazy")
+  uint32_t rec;                  // big-list kernel, three message planes, L >= 32 and a multiple of 4: RECORD layout.  A (ring, crf) list is
+                                 //   [conv N][entry L][8 words: score, fingerprint, message words 4-5, message words 0-3]
+                                 // instead of L blocks of conv-fastest planes: the entries of one conv state's list are adjacent
+                                 // (4 per 128-byte line), so a thread that walks a list pulls each line once instead of one line
+                                 // per entry, and an entry is one line instead of three (same footprint: sCrf = N*L*8 words)
   uint64_t sCrf, sRing, sPar, sSlot;
 };
 
-inline Geometry make_geometry(uint32_t N, uint32_t L, uint32_t msg_bits, uint32_t R, uint32_t lazy = 0) {
+inline Geometry make_geometry(uint32_t N, uint32_t L, uint32_t msg_bits, uint32_t R, uint32_t lazy = 0, uint32_t rec = 0) {
   Geometry g;
   g.N = N; g.L = L; g.P = (msg_bits + 63) / 64; if (g.P == 0) g.P = 1;
   g.W = 2 * g.P; g.F = g.W + 2; g.R = R;
-  g.lazy = lazy;
+  g.lazy = lazy; g.rec = (rec && !lazy && g.P == 3 && L >= 32 && L % 4 == 0) ? 1u : 0u;   // (below 32 entries the plane layout is faster: measured)
   g.sBlk = N * g.F;
   // lazy mode: behind the L entry blocks of a (ring, crf) list, L back-pointer bytes per conv state ([conv][entry])
   g.sCrf = (uint64_t)g.sBlk * L + (lazy ? (uint64_t)N * L / 4 : 0); g.sRing = g.sCrf * 8;

@@ -192,6 +192,22 @@ __device__ __forceinline__ uint32_t msg_word(const Geometry& g, const uint32_t* 
   return (w >> 1) < np ? buf[blk + 2 * g.N + msg_word_off(g.N, c, w, np)] : 0u;
 }
 
+// Either layout (Geometry::rec, lva_device.h): entry l of conv state c of the list that starts at word `list`.
+//   rec_sh    word offset of its (score, fingerprint) pair
+//   rec_word  word offset of its message word w (np = planes in use at the entry's position; the record layout carries all six)
+// Record = 8 words: score, fingerprint, message words 4-5, message words 0-3.
+__device__ __forceinline__ uint32_t rec_sh(const Geometry& g, uint32_t list, uint32_t c, uint32_t l) {
+  return g.rec ? list + (c * g.L + l) * 8u : list + l * g.sBlk + 2 * c;
+}
+__device__ __forceinline__ uint32_t rec_word(const Geometry& g, uint32_t list, uint32_t c, uint32_t l, uint32_t w, uint32_t np) {
+  return g.rec ? list + (c * g.L + l) * 8u + (w < 4 ? 4u + w : w - 2u) : list + l * g.sBlk + 2 * g.N + msg_word_off(g.N, c, w, np);
+}
+// message word w of that entry; words in planes that are not in use at the entry's position are zero
+__device__ __forceinline__ uint32_t entry_word(const Geometry& g, const uint32_t* __restrict__ buf, uint32_t list, uint32_t c, uint32_t l,
+                                               uint32_t w, uint32_t np) {
+  return (w >> 1) < np ? buf[rec_word(g, list, c, l, w, np)] : 0u;
+}
+
 // message of an entry (layout: msg_word_off above).  `ent` = the entry's block base + 2N (start of
 // its message region); words in planes >= np are zero and are not read
 template <int P> __device__ __forceinline__ void load_msg(const uint32_t* __restrict__ ent, uint32_t N, uint32_t c, uint32_t np,
@@ -615,14 +631,14 @@ __device__ __forceinline__ void wave_target(const Geometry& g, const SlotStep& s
   const uint32_t L = g.L, sBlk = g.sBlk, sCrf = (uint32_t)g.sCrf;
   const uint32_t Wd = 2 * tg.np_dst;
   const float NEG = -INFINITY;
-  const uint32_t own_sh = tg.own + 2 * tg.c;
+  const uint32_t own_sh = rec_sh(g, tg.own, tg.c, 0);
   if (pos == 0) {                                                      // :706-713
     if (lane == 0) {
       cur[own_sh] = f2u(u2f(prev[own_sh]) + ss.post_row[tg.row * 8 + k]);
       cur[own_sh + 1] = prev[own_sh + 1];
     }
-    if (lane < Wd) cur[tg.own + 2 * g.N + msg_word_off(g.N, tg.c, lane, tg.np_dst)] = prev[tg.own + 2 * g.N + msg_word_off(g.N, tg.c, lane, tg.np_dst)];
-    if (lane >= 1 && lane < L) cur[own_sh + lane * sBlk] = kNegInfBits;
+    if (lane < (g.rec ? 6u : Wd)) cur[rec_word(g, tg.own, tg.c, 0, lane, tg.np_dst)] = prev[rec_word(g, tg.own, tg.c, 0, lane, tg.np_dst)];
+    if (lane >= 1 && lane < L) cur[rec_sh(g, tg.own, tg.c, lane)] = kNegInfBits;
     return;
   }
   auto rdf = [](float v, uint32_t ln) -> float { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)ln)); };
@@ -635,7 +651,7 @@ __device__ __forceinline__ void wave_target(const Geometry& g, const SlotStep& s
   for (uint32_t i = 0; i < 8; ++i) {
     cs[i] = NEG; cy[i] = 0;
     if (i < tg.nlists && ((tg.okmask >> i) & 1u) && lane < L) {
-      const uint32_t b = (i == 0 ? tg.own : tg.src + list_crf(k, i) * sCrf) + lane * sBlk + 2 * (i == 0 ? tg.c : tg.cp);
+      const uint32_t b = rec_sh(g, i == 0 ? tg.own : tg.src + list_crf(k, i) * sCrf, i == 0 ? tg.c : tg.cp, lane);
       const uint2 v = *reinterpret_cast<const uint2*>(prev + b);
       cs[i] = u2f(v.x); cy[i] = i != 0 ? v.y ^ tg.fpc : v.y;
     }
@@ -656,11 +672,11 @@ __device__ __forceinline__ void wave_target(const Geometry& g, const SlotStep& s
   if (lane < tg.nlists) addv = ss.post_row[tg.row * 8 + (lane == 0 ? k : list_crf(k, lane))];
   // word w of the candidate message built from entry (li, lj): per-lane arguments allowed
   auto word_of = [&](uint32_t li, uint32_t lj, uint32_t w) -> uint32_t {
-    const uint32_t b = (li == 0 ? tg.own : tg.src + list_crf(k, li) * sCrf) + lj * sBlk;
+    const uint32_t lst = li == 0 ? tg.own : tg.src + list_crf(k, li) * sCrf;
     const uint32_t cv = li == 0 ? tg.c : tg.cp, np = li == 0 ? tg.np_dst : tg.np_src;
-    const uint32_t v = msg_word(g, prev, b, cv, w, np);
+    const uint32_t v = entry_word(g, prev, lst, cv, lj, w, np);
     if (li == 0) return v;
-    const uint32_t lowpart = w == 0 ? tg.newbits : (msg_word(g, prev, b, cv, w - 1, np) >> (32 - tg.shift));
+    const uint32_t lowpart = w == 0 ? tg.newbits : (entry_word(g, prev, lst, cv, lj, w - 1, np) >> (32 - tg.shift));
     return (v << tg.shift) | lowpart;
   };
   // 2. the reference merge (:743-800): GCC 11 bits/stl_heap.h restated on lane-resident arrays
@@ -729,14 +745,26 @@ __device__ __forceinline__ void wave_target(const Geometry& g, const SlotStep& s
   }
   // 3. outputs: lane a writes list entry a (:781, :799) and, if accepted, its message
   if (lane < L) {
-    *reinterpret_cast<uint2*>(cur + own_sh + lane * sBlk) = lane < l ? make_uint2(f2u(as), ay) : make_uint2(kNegInfBits, 0u);
+    *reinterpret_cast<uint2*>(cur + rec_sh(g, tg.own, tg.c, lane)) = lane < l ? make_uint2(f2u(as), ay) : make_uint2(kNegInfBits, 0u);
     if (lane < l) {          // the whole message in the widest pieces the layout has (not word by word: every access of a lane is its own line)
       const uint32_t li = ax >> 16, lj = ax & 0xFFFFu;
-      const uint32_t b = (li == 0 ? tg.own : tg.src + list_crf(k, li) * sCrf) + lj * sBlk + 2 * g.N;
+      const uint32_t lst = li == 0 ? tg.own : tg.src + list_crf(k, li) * sCrf, cv = li == 0 ? tg.c : tg.cp;
       uint32_t m[8];
-      load_msg<4>(prev + b, g.N, li == 0 ? tg.c : tg.cp, li == 0 ? tg.np_dst : tg.np_src, m);
-      push_bits<8>(m, li == 0 ? 0u : tg.shift, tg.newbits);
-      store_msg<4>(cur + tg.own + lane * sBlk + 2 * g.N, g.N, tg.c, tg.np_dst, m);
+      if (g.rec) {           // record layout: all six words of every stored entry are valid (zero in planes not yet in use)
+        const uint32_t* rp = prev + rec_sh(g, lst, cv, lj);
+        const lva_u32x4 lo = *LVA_GLOBAL(lva_u32x4, rp + 4);
+        const lva_u32x2 hi = *LVA_GLOBAL(lva_u32x2, rp + 2);
+        m[0] = lo.x; m[1] = lo.y; m[2] = lo.z; m[3] = lo.w; m[4] = hi.x; m[5] = hi.y; m[6] = 0; m[7] = 0;
+        push_bits<8>(m, li == 0 ? 0u : tg.shift, tg.newbits);
+        uint32_t* wp = cur + rec_sh(g, tg.own, tg.c, lane);
+        const lva_u32x4 out = {m[0], m[1], m[2], m[3]};
+        *reinterpret_cast<lva_u32x4*>(wp + 4) = out;
+        wp[2] = m[4]; wp[3] = m[5];
+      } else {
+        load_msg<4>(prev + lst + lj * sBlk + 2 * g.N, g.N, cv, li == 0 ? tg.np_dst : tg.np_src, m);
+        push_bits<8>(m, li == 0 ? 0u : tg.shift, tg.newbits);
+        store_msg<4>(cur + tg.own + lane * sBlk + 2 * g.N, g.N, tg.c, tg.np_dst, m);
+      }
     }
   }
 }
@@ -1966,6 +1994,278 @@ __global__ __launch_bounds__(8 * TSB) void lva_step_big(StepArgs args, Geometry 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Big-list kernel on the RECORD layout (Geometry::rec: three message planes, L a multiple of 4).
+//
+// What bounds lva_step_big is the number of cache lines it pulls, not instructions and not latency: per target and step
+// ~80 list heads + 64 re-reads of accepted (score, fingerprint) pairs + 128 message pieces, each an 8- or 16-byte access
+// to its own line of a conv-fastest row -- rocprofv3 (round 3): 2.8x the algorithmic bytes at ~5.7 TB/s.  Every variant
+// that changed the number of operations without changing the number of lines lost (16-byte units, 16-conv tiles,
+// non-temporal message loads, more workgroups per CU: round 4).  Here the entries of ONE conv state's list are adjacent
+// -- [conv][entry][score, fingerprint, words 4-5, words 0-3], four records per 128-byte line -- so
+//   * a thread that walks a list (the merge pops ~46 of a target's 64 entries from one source list) pulls a line per
+//     four entries instead of one per entry;
+//   * an accepted entry is ONE line (two 16-byte loads: score and fingerprint come with the message) instead of three;
+//   * a target's output is 2 KB contiguous.  Threads cannot store it themselves (64 partial lines per instruction:
+//     measured 1.6x slower in round 2): each wavefront passes four entries of its 64 targets through LDS and stores
+//     whole 128-byte lines, eight targets per instruction.  For that the wavefront stays whole: threads without a target,
+//     and threads whose target goes to the work list, keep running as store helpers.
+// One fingerprint-match slot per accepted entry (a second match is reason 3: the exact path decides).
+// Same decisions as big_merge otherwise; ties, non-finite sums and collisions go to lva_step_fixup_wave, which reads and
+// writes the same layout (rec_sh / rec_word).
+// ---------------------------------------------------------------------------------------
+namespace {
+
+constexpr uint32_t kTrRow = 36;      // words per thread in the transpose buffer: 4 records + 4 words of padding (conflict-free b128)
+
+template <int LL, int NL>
+__device__ __forceinline__ int big_merge_rec(const Geometry& g, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur,
+                                              const float* s_post, uint8_t* s_acc, uint8_t* s_rej0, uint32_t* s_tr, uint32_t* s_base,
+                                              bool valid, const TileTarget& t, uint32_t src) {
+  constexpr uint32_t NT = 8 * TSB;
+  const float NEG = -INFINITY;
+  const uint32_t L = g.L, sCrf = (uint32_t)g.sCrf;
+  const uint32_t lane = threadIdx.x & 63u, wrow = threadIdx.x & ~63u;     // first thread of this wavefront
+  const uint32_t k = t.k, row = k >= 4 ? 4u : k;
+  const uint32_t own_r = t.own + mul24(t.c, L) * 8u, src_r = src + mul24(t.cp, L) * 8u;   // record 0 of the own / of a source list 0
+  auto lrec = [&](uint32_t i) -> uint32_t { return i == 0 ? own_r : src_r + mul24(list_crf(k, i), sCrf); };
+  auto ladd = [&](uint32_t i) -> float { return s_post[row * 8 + (i == 0 ? k : list_crf(k, i))]; };
+  int why = 0;
+  uint32_t lc = 0;
+  unsigned long long acc_hi = 0, rv0 = 0, rh0 = 0;
+
+  if (valid) {
+    float h[NL]; uint32_t hf[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {                                       // list heads (:750-761)
+      h[i] = NEG; hf[i] = 0;
+      if ((t.ok >> i) & 1u) {
+        const lva_u32x2 v = *LVA_GLOBAL(lva_u32x2, prev + lrec(i));
+        const bool ok = u2f(v.x) != NEG;
+        h[i] = ok ? u2f(v.x) + ladd(i) : NEG;
+        if (ok && !(h[i] > NEG)) why = 2;                  // non-finite sum: the exact path decides
+        hf[i] = i ? v.y ^ t.fpc : v.y;
+      }
+    }
+    uint32_t ah[LL];                 // accepted fingerprints, NEWEST FIRST (shift register: static indices only)
+#pragma unroll
+    for (int l = 0; l < LL; ++l) ah[l] = 0;
+    unsigned long long ptr = 0;      // 7 bits per list: entries consumed
+    bool rej_full = false;
+    // one pop (:766-785) of entry (sel, jj) with fingerprint fp, for the threads in `pred`: de-duplicate on fingerprints
+    // (position q in ah <-> accepted entry lc-1-q), file the entry or the match.  Entries at positions >= lc are unused (zero,
+    // never a valid match), so the scan and the shift only touch the 16-entry segments some thread of the wavefront has reached.
+    auto pop = [&](bool pred, uint32_t sel, uint32_t jj, uint32_t fp) __attribute__((always_inline)) {
+      bool seg[LL / 16];
+#pragma unroll
+      for (int sg = 1; sg < LL / 16; ++sg) seg[sg] = __ballot(lc >= 16u * sg) != 0ull;
+      int q = -1;
+#pragma unroll
+      for (int sg = LL / 16 - 1; sg >= 1; --sg)
+        if (seg[sg]) {
+#pragma unroll
+          for (int a = 16 * sg + 15; a >= 16 * sg; --a) q = ah[a] == fp ? a : q;
+        }
+#pragma unroll
+      for (int a = 15; a >= 0; --a) q = ah[a] == fp ? a : q;
+      const bool isdup = q >= 0 && (uint32_t)q < lc;
+      const bool accept = pred && !isdup, reject = pred && isdup;
+      const uint32_t from9 = (sel << 6) | jj;
+      const unsigned long long hi9 = (unsigned long long)(sel >> 2);
+      if (accept) s_acc[lc * NT] = (uint8_t)from9;
+      acc_hi |= accept ? hi9 << lc : 0ull;
+      const uint32_t ra = lc - 1u - (uint32_t)q;                 // the entry it matched (only meaningful when reject)
+      const unsigned long long rbit = 1ull << (ra & 63u);
+      const bool use0 = reject && !(rv0 & rbit);
+      rej_full = rej_full || (reject && !use0);
+      if (use0) s_rej0[ra * NT] = (uint8_t)from9;
+      rv0 |= use0 ? rbit : 0ull; rh0 |= (use0 && hi9) ? rbit : 0ull;
+#pragma unroll
+      for (int sg = LL / 16 - 1; sg >= 1; --sg)
+        if (seg[sg]) {
+#pragma unroll
+          for (int a = 16 * sg + 15; a >= 16 * sg; --a) ah[a] = selv(accept, ah[a - 1], ah[a]);
+        }
+#pragma unroll
+      for (int a = 15; a >= 1; --a) ah[a] = selv(accept, ah[a - 1], ah[a]);
+      ah[0] = selv(accept, fp, ah[0]);
+      lc += accept ? 1u : 0u;
+    };
+    bool go = why == 0;
+    while (go) {                                                         // :764
+      float M = h[0];
+#pragma unroll
+      for (int i = 1; i < NL; ++i) M = fmaxf(M, h[i]);
+      bool eq[NL];
+#pragma unroll
+      for (int i = 0; i < NL; ++i) eq[i] = h[i] == M;
+      uint32_t sel = NL - 1, last = 0;   // first / last head equal to the maximum: they differ on a tie
+#pragma unroll
+      for (int i = NL - 2; i >= 0; --i) sel = eq[i] ? (uint32_t)i : sel;
+#pragma unroll
+      for (int i = 1; i < NL; ++i) last = eq[i] ? (uint32_t)i : last;
+      const bool two = sel != last;
+      const bool alive = M > NEG;            // false: every list exhausted (heap empty)
+      const bool proceed = alive && !two;
+      const uint32_t j = (uint32_t)(ptr >> (7 * sel)) & 127u;
+      // next entry of the popped list -- the neighbouring record: requested now, used after the scan (:788-796)
+      const bool has_next = j + 1 < L;
+      const lva_u32x2 nv = *LVA_GLOBAL(lva_u32x2, prev + lrec(sel) + (has_next ? j + 1 : j) * 8u);
+      uint32_t ch = hf[NL - 1];
+#pragma unroll
+      for (int i = NL - 2; i >= 0; --i) ch = selv(eq[i], hf[i], ch);
+      pop(proceed, sel, j, ch);
+      const float addsel = ladd(sel);
+      const bool nxt_ok = has_next && u2f(nv.x) != NEG;
+      const float ns = nxt_ok ? u2f(nv.x) + addsel : NEG;
+      const bool bad = nxt_ok && !(ns > NEG);   // overflowed to -inf: the reference would still queue it
+      const uint32_t nf = sel ? nv.y ^ t.fpc : nv.y;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) { h[i] = selv(eq[i], ns, h[i]); hf[i] = selv(eq[i], nf, hf[i]); }
+      ptr += 1ull << (7 * sel);
+      why = (alive && two) ? 1 : ((proceed && bad) ? 2 : (rej_full ? 3 : 0));
+      go = proceed && why == 0 && lc < L;
+    }
+  }
+
+  // ---- outputs: the whole wavefront, four entries of every target at a time (:771-774, :780-783, :799) ----
+  const bool act = valid && why == 0;                     // this thread's target is written here (else: not stored / the exact path)
+  s_base[threadIdx.x] = act ? own_r : 0xFFFFFFFFu;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  auto locate = [&](uint32_t from9, uint32_t* i_out) -> uint32_t {   // record of entry `from9` of the previous step
+    const uint32_t i = from9 >> 6, j = from9 & 63u;
+    *i_out = i;
+    return lrec(i) + j * 8u;
+  };
+  bool good = true;
+  // the transpose buffer holds the four records of HALF a wavefront's targets (32 rows per wavefront): 51 KB of LDS per
+  // workgroup instead of 70 KB -- three workgroups per CU, which is what this latency-bound kernel needs (12 wavefronts per CU)
+  const uint32_t half = lane >> 5;
+  uint32_t* trow = s_tr + ((wrow >> 1) + (lane & 31u)) * kTrRow;
+  for (uint32_t l0 = 0; l0 < L; l0 += 4) {
+    lva_u32x4 ra4[4], rb4[4], oa[4], ob[4]; uint32_t q0[4][6]; uint32_t iu[4], ir[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      const uint32_t l = l0 + u;
+      iu[u] = 0; ir[u] = 0;
+      if (act && l < lc) {
+        const uint32_t f = locate((uint32_t)s_acc[l * NT] | ((uint32_t)(acc_hi >> l) & 1u) << 8, &iu[u]);
+        ra4[u] = *LVA_GLOBAL(lva_u32x4, prev + f);          // score, fingerprint, words 4-5
+        rb4[u] = *LVA_GLOBAL(lva_u32x4, prev + f + 4);      // words 0-3
+        if ((rv0 >> l) & 1ull) {          // the match filed under this entry: its loads travel with the others
+          const uint32_t fr = locate((uint32_t)s_rej0[l * NT] | ((uint32_t)(rh0 >> l) & 1u) << 8, &ir[u]);
+          const lva_u32x4 a = *LVA_GLOBAL(lva_u32x4, prev + fr + 4);
+          const lva_u32x2 b = *LVA_GLOBAL(lva_u32x2, prev + fr + 2);
+          q0[u][0] = a.x; q0[u][1] = a.y; q0[u][2] = a.z; q0[u][3] = a.w; q0[u][4] = b.x; q0[u][5] = b.y;
+        }
+      }
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      const uint32_t l = l0 + u;
+      oa[u] = lva_u32x4{kNegInfBits, 0u, 0u, 0u}; ob[u] = lva_u32x4{0u, 0u, 0u, 0u};      // (:799) the unused tail of the list
+      if (act && l < lc) {
+        uint32_t m[6] = {rb4[u].x, rb4[u].y, rb4[u].z, rb4[u].w, ra4[u].z, ra4[u].w};
+        const float sc = u2f(ra4[u].x) + ladd(iu[u]);
+        push_var<6>(m, iu[u] == 0 ? 0u : t.sh, iu[u] == 0 ? 0u : t.nb);
+        oa[u].x = f2u(sc); oa[u].y = iu[u] ? ra4[u].y ^ t.fpc : ra4[u].y; oa[u].z = m[4]; oa[u].w = m[5];
+        ob[u].x = m[0]; ob[u].y = m[1]; ob[u].z = m[2]; ob[u].w = m[3];
+        if ((rv0 >> l) & 1ull) {
+          push_bits<6>(q0[u], ir[u] == 0 ? 0u : t.sh, t.nb);
+#pragma unroll
+          for (int w = 0; w < 6; ++w) good &= (q0[u][w] == m[w]);
+        }
+      }
+    }
+    // whole lines out, half a wavefront's targets per round: instruction s stores the 128 bytes (4 records) of targets
+    // 32h + 8s .. 32h + 8s + 7, 16 bytes per thread
+#pragma unroll
+    for (uint32_t h2 = 0; h2 < 2; ++h2) {
+      if (half == h2) {
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+          *reinterpret_cast<lva_u32x4*>(trow + 8 * u) = oa[u];
+          *reinterpret_cast<lva_u32x4*>(trow + 8 * u + 4) = ob[u];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (uint32_t s8 = 0; s8 < 4; ++s8) {
+        const uint32_t Tl = 8 * s8 + (lane >> 3), piece = lane & 7u;       // target (local to the half), 16-byte piece of its line
+        const uint32_t base = s_base[wrow + 32 * h2 + Tl];
+        if (base != 0xFFFFFFFFu) {
+          const lva_u32x4 v = *reinterpret_cast<const lva_u32x4*>(s_tr + ((wrow >> 1) + Tl) * kTrRow + 4 * piece);
+          uint32_t* dst = cur + base + l0 * 8u + 4 * piece;
+          __builtin_nontemporal_store(v.x, dst); __builtin_nontemporal_store(v.y, dst + 1);
+          __builtin_nontemporal_store(v.z, dst + 2); __builtin_nontemporal_store(v.w, dst + 3);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (!valid) return 0;
+  if (why) return why;
+  return good ? 0 : 4;
+}
+
+}  // namespace
+
+// grid: x = tiles of TSB source conv states, y = band position index, z = slot index; 256 threads (as lva_step_big).
+template <int LL>
+__global__ __launch_bounds__(8 * TSB) void lva_step_big_rec(StepArgs args, Geometry g, const DevCode* __restrict__ codes,
+                                                          uint32_t* __restrict__ trellis, WorkHdr* __restrict__ hdr,
+                                                          uint32_t* __restrict__ items) {
+  __shared__ uint8_t s_acc[LL * 8 * TSB], s_rej0[LL * 8 * TSB];
+  __shared__ uint32_t s_tr[4 * TSB * kTrRow];        // 32 rows per wavefront
+  __shared__ uint32_t s_base[8 * TSB];
+  __shared__ float s_post[40];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+    hdr->count[args.step_parity ^ 1u] = 0;     // the other parity's list was consumed by the last fix-up
+    hdr->overflow[args.step_parity ^ 1u] = 0;
+  }
+  SlotStep ss;
+  if (!load_slot(args, blockIdx.z, &ss)) return;
+  const uint32_t pos = ss.lo + blockIdx.y;
+  if (pos >= ss.hi) return;
+  const DevCode& cd = codes[ss.orient];
+  const uint32_t tid = threadIdx.x, tile = blockIdx.x;
+  const uint32_t* prev; uint32_t* cur;
+  slot_buffers(ss, g, trellis, &prev, &cur);
+
+  if (pos == 0) {                          // stay-only update of the 8 start states (:706-713)
+    if (tile == cd.init / TSB && tid < 8) {
+      const uint32_t k = tid, c = cd.init;
+      const uint32_t lst = (uint32_t)((uint64_t)k * g.sCrf), r0 = rec_sh(g, lst, c, 0);
+      const float s = u2f(prev[r0]) + ss.post_row[(k >= 4 ? 4u : k) * 8 + k];
+      cur[r0] = f2u(s);
+      for (uint32_t w = 1; w < 8; ++w) cur[r0 + w] = prev[r0 + w];      // fingerprint and the (empty) message
+      for (uint32_t l = 1; l < g.L; ++l) cur[rec_sh(g, lst, c, l)] = kNegInfBits;
+    }
+    return;
+  }
+  if (tid < 40) s_post[tid] = LVA_GLOBAL(float, ss.post_row)[tid];
+  __syncthreads();
+
+  const uint32_t src = (uint32_t)((uint64_t)((pos - 1) % g.R) * 8 * g.sCrf);
+  TileTarget t;
+  t.c = 0; t.cp = 0; t.sc = 0; t.k = (tid / (4 * TSB)) * 4; t.sh = 1; t.nb = 0; t.fpc = 0; t.np_dst = 1; t.np_src = 1; t.ok = 0; t.own = 0;
+  t.base = 0; t.reach = 0; t.pk1 = 0;
+  const bool valid = tile_target<TSB>(cd, g, ss, pos, tile, tid, &t);
+  // (wavefronts 0-1 hold the flip targets, 2-3 the flop targets: the merge width is uniform per wavefront)
+  const int why = tid < 4 * TSB ? big_merge_rec<LL, 8>(g, prev, cur, s_post, s_acc + tid, s_rej0 + tid, s_tr, s_base, valid, t, src)
+                                : big_merge_rec<LL, 2>(g, prev, cur, s_post, s_acc + tid, s_rej0 + tid, s_tr, s_base, valid, t, src);
+  if (why) {
+    atomicAdd(&hdr->reason[why - 1], 1ull);
+    const uint32_t idx = atomicAdd(&hdr->count[args.step_parity], 1u);
+    if (idx < hdr->cap) items[idx] = make_item(cd.m, blockIdx.z, blockIdx.y, t.k, t.c);
+    else hdr->overflow[args.step_parity] = 1u;
+  }
+}
+
 // One thread per read slot: resolve descriptor -> time step -> band of this launch into the SlotStep record the
 // step kernels read (small trellises run hundreds of slots per launch, and every workgroup of a slot would otherwise
 // walk the same chain of dependent loads, cold, by itself).
@@ -1997,7 +2297,10 @@ __global__ void lva_init_slot(Geometry g, const DevCode* __restrict__ codes, uin
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
     const uint32_t f = i % g.F, l = (i / g.F) % g.L, k = i / (g.F * g.L);
     const uint64_t blk = (uint64_t)k * g.sCrf + (uint64_t)l * g.sBlk;     // ring slot 0 = position 0
-    par0[blk + plane_off(g, f >> 1, cd.init) + (f & 1u)] = (f == 0 && l > 0) ? kNegInfBits : 0u;
+    const uint64_t at = g.rec ? (f < 2 ? rec_sh(g, (uint32_t)((uint64_t)k * g.sCrf), cd.init, l) + f
+                                       : rec_word(g, (uint32_t)((uint64_t)k * g.sCrf), cd.init, l, f - 2, 3))
+                              : blk + plane_off(g, f >> 1, cd.init) + (f & 1u);
+    par0[at] = (f == 0 && l > 0) ? kNegInfBits : 0u;
   }
 }
 
@@ -2067,8 +2370,8 @@ __global__ void lva_gather_final(Geometry g, const DevCode* __restrict__ codes, 
     const uint32_t f = i % g.F, l = (i / g.F) % g.L, k = i / (g.F * g.L);
     uint32_t v = f == 0 ? kNegInfBits : 0u;
     if (((reach >> k) & 1u) && (f < 2 || ((f - 2) >> 1) < np)) {
-      const uint32_t blk = (uint32_t)((((uint64_t)(pos % g.R) * 8 + k) * g.L + l) * g.sBlk);
-      v = f < 2 ? buf[blk + 2 * c + f] : msg_word(g, buf, blk, c, f - 2, np);
+      const uint32_t lst = (uint32_t)(((uint64_t)(pos % g.R) * 8 + k) * g.sCrf);
+      v = f < 2 ? buf[rec_sh(g, lst, c, l) + f] : entry_word(g, buf, lst, c, l, f - 2, np);
     }
     out[i] = v;
   }
@@ -2134,6 +2437,12 @@ int launch_step_fast(const StepArgs& a, const Geometry& g, const DevCode* codes,
   hipStream_t st = (hipStream_t)stream;
   int e;
   if (!small_list(g)) {   // big-list kernel + wavefront-per-target fix-up
+    if (g.rec) {          // record layout (three message planes, 32 <= L <= 64, L a multiple of 4)
+      dim3 grid(g.N / TSB, a.band_max, a.nslots), block(8 * TSB);
+      if (g.L <= 32) hipLaunchKernelGGL((lva_step_big_rec<32>), grid, block, 0, st, a, g, codes, trellis, hdr, items);
+      else hipLaunchKernelGGL((lva_step_big_rec<64>), grid, block, 0, st, a, g, codes, trellis, hdr, items);
+      e = (int)hipGetLastError();
+    } else
     e = g.L <= 16 ? launch_big_p<16>(a, g, codes, trellis, hdr, items, st)
       : g.L <= 32 ? launch_big_p<32>(a, g, codes, trellis, hdr, items, st)
                   : launch_big_p<64>(a, g, codes, trellis, hdr, items, st);

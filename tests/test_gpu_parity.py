@@ -183,15 +183,16 @@ def test_big_list_kernel_work_list_overflow(oracle, monkeypatch):
     _compare(oracle, 6, 1, 40, 16, 20, reads, kernel=2)
 
 
-@pytest.mark.parametrize("L", [5, 16, 64])
+@pytest.mark.parametrize("L", [5, 16, 36, 64])
 def test_big_list_kernel_three_planes_tie_stress(oracle, L):
-    """three message planes (lva_step_big<LL,3>, the benchmark's message width): ties send most targets through the
-    wavefront fix-up, which reads and writes the same rows"""
+    """three message planes (the benchmark's message width): lva_step_big<LL,3> on the plane layout below 32 entries,
+    lva_step_big_rec<LL> on the record layout from 32 on (L a multiple of 4; 36 = a list shorter than the instance's 64) --
+    ties send most targets through the wavefront fix-up, which reads and writes the same layout"""
     reads = [synth.make_read(6, 1, 150, 960 + i, rc=bool(i & 1), margin=2.0, quantum=0.5) for i in range(2)]
     _compare(oracle, 6, 1, 150, L, 20, reads, kernel=2)
 
 
-@pytest.mark.parametrize("L,md", [(16, 20), (12, 3)])
+@pytest.mark.parametrize("L,md", [(32, 20), (12, 3), (40, 2)])
 def test_big_list_kernel_three_planes_overflow_and_turnover(oracle, monkeypatch, L, md):
     """three message planes: whole-step redo on the wavefront path (4-entry work list), then 40 reads of odd and even block counts
     through 3 slots with tiny and full bands (stale ring contents, position 0 rewritten by later reads)"""
@@ -199,7 +200,7 @@ def test_big_list_kernel_three_planes_overflow_and_turnover(oracle, monkeypatch,
     monkeypatch.setenv("LVA_WORK_CAP", "4")
     _compare(oracle, 6, 1, 150, L, md, reads, kernel=2, max_slots=2)
     monkeypatch.delenv("LVA_WORK_CAP")
-    reads = [synth.make_read(6, 1, 150, 7700 + i, rc=bool(i % 3 == 0), margin=2.5 + (i % 3)) for i in range(14 if md > 10 else 40)]
+    reads = [synth.make_read(6, 1, 150, 7700 + i, rc=bool(i % 3 == 0), margin=2.5 + (i % 3)) for i in range(10 if md > 10 else 40)]
     assert len({x["post"].shape[0] & 1 for x in reads}) == 2
     _compare(oracle, 6, 1, 150, L, md, reads, kernel=0, max_slots=3)
 
