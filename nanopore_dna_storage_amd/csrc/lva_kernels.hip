@@ -6,26 +6,27 @@
 // the body of the reference's time loop (viterbi/viterbi_convolutional_code.cpp:685-804),
 // with identical results.
 //
-// Kernels
-//   lva_step_fast<L,P>  butterfly-tiled fast path.  One workgroup = one (slot, position, tile
-//                    of 64 source conv states); the (score, fingerprint) pairs of all source
-//                    lists are staged once into LDS with fully coalesced 16-byte loads and
-//                    shared by the 64 target conv states x up to 4 bases that consume them.
-//                    Wavefronts 0-3 merge the flip targets (8 lists each), wavefronts 4-7 the
-//                    flop targets (2 lists), one target per thread: a register tournament over
-//                    the list heads, de-duplication on message fingerprints, then a gather of
-//                    only the surviving messages from HBM (each fingerprint match is verified
-//                    on the full message) and coalesced stores.  Whenever the result could
-//                    depend on libstdc++'s heap order (equal scores on top), on non-finite
-//                    arithmetic or on a fingerprint collision, the target is queued for the
-//                    exact path instead.
-//   lva_step_fixup   exact path behind the fast kernel: one wavefront per queued target, the
-//                    candidate heads staged in LDS, the reference's heap merge (:743-800)
-//                    replayed literally, outputs written cooperatively.
-//   lva_step_wave    the literal merge with one wavefront per target over the whole step: list
-//                    sizes 2..64 that have no fast kernel (kernel mode 3).
-//   lva_step_exact   one thread per target state, the same literal merge straight from HBM --
-//                    any list size; kernel mode 1 and the overflow path of the fix-up.
+// Kernels (which one runs: lva_api.cpp lva_decoder_create)
+//   lva_step_lazy<L,P,ANCHOR>  list sizes 2 / 4 / 8 (the default there, kernel mode 4).  Butterfly tile: one workgroup =
+//                    one (slot, position, tile of 64 source conv states); the (score, fingerprint) pairs of all
+//                    source lists are staged once into LDS with coalesced 16-byte loads and shared by the target
+//                    conv states x up to 4 bases that consume them.  Wavefronts 0-3 merge the flip targets (8 lists),
+//                    4-7 the flop targets (2 lists), one target per thread: a register tournament over the list
+//                    heads, de-duplication on message fingerprints (every match verified on the full message).
+//                    Messages are materialised on even time steps only ("anchor" instance: two hops to the stored
+//                    message); odd steps store one back-pointer byte per entry.  A launch runs one instance: the host
+//                    keeps all slots at the same step parity.  Equal scores on top, non-finite arithmetic and
+//                    fingerprint collisions queue the target for the exact path.
+//   lva_step_fixup_lazy   that exact path: one wavefront per queued target, the reference's heap merge (:743-800)
+//                    replayed literally on lane-resident values.
+//   lva_step_fast<L,P> + lva_step_fixup   the same tile with messages moved on every step (kernel mode 2 at L = 2/4/8).
+//   lva_step_acs<P>  L = 1: plain add-compare-select on the same tile, 256 threads.
+//   lva_step_big<LL,P> / lva_step_big_rec<LL> + lva_step_fixup_wave   other list sizes up to 64: list heads read on
+//                    demand; plane layout / record layout (Geometry::rec).
+//   lva_step_wave    the literal merge with one wavefront per target over the whole step (kernel mode 3).
+//   lva_step_exact   one thread per target state, the same literal merge straight from HBM -- any list size; kernel
+//                    mode 1, the default above 64 entries, and the overflow path of lva_step_fixup.
+//   lva_prepare_step per launch: slot descriptor -> this launch's SlotStep record of every slot
 //   lva_init_slot    initial scores (:657-663)
 //   lva_gather_final final state's lists -> result record (:806-815)
 #include <hip/hip_runtime.h>
