@@ -57,6 +57,10 @@ def test_bench_starts_its_own_ranks(tmp_path):
     j1, z1 = _bench(["--gpus", "1"] + SMALL, {"LVA_BENCH_SPAWN": "1"}, tmp_path, "one")
     assert j2["n_gpus"] == 2 and j1["n_gpus"] == 1
     assert j2["scaling"] == "strong" and j2["config"]["gathered_lists"] == 10
+    # every rank reports its own rate, launch time and slot occupancy (a bad scaling point names its rank)
+    pr = j2["config"]["per_rank"]
+    assert [x["rank"] for x in pr] == [0, 1] and all(x["reads_s"] > 0 and x["avg_launch_ms"] > 0 and x["mean_active_slots"] > 0 for x in pr)
+    assert j1["config"]["per_rank"] is None or len(j1["config"]["per_rank"]) == 1
     for k in ("counts", "msgs"):
         assert np.array_equal(z1[k], z2[k])
     assert np.array_equal(z1["scores"].view(np.uint32), z2["scores"].view(np.uint32))

@@ -231,6 +231,15 @@ def test_list_files_are_written_atomically(tmp_path):
     gdl.write_list_file(str(p), np.array([[1, 0, 1], [0, 0, 1]], np.uint8))
     assert p.read_text() == "101\n001\n"
     assert [f.name for f in tmp_path.iterdir()] == ["list_7"]
+    # a temporary file a killed run left behind never looks like a list file (list consumers take list_<digits> only) and is
+    # removed by the next run
+    stale = tmp_path / (gdl.TMP_PREFIX + "list_9-12345")
+    stale.write_text("10")
+    from nanopore_dna_storage_amd import compute_error_rate_from_decoded_lists as cer
+    (tmp_path / "list_7.bak").write_text("1\n")
+    assert [n for n, _ in cer.read_lists(str(tmp_path))] == ["list_7"]
+    gdl.remove_stale_temp_files(str(tmp_path / "list"))
+    assert not stale.exists() and p.exists()
     args = gdl.build_parser().parse_args(["--post_manifest", "m", "--out_prefix", "o", "--info_file", "i", "--mem_conv", "6", "--msg_len", "60",
                                           "--rate_conv", "1", "--list_size", "4"])
     assert args.chunk == 4096 and args.max_deviation == 20 and args.gpus == 1
