@@ -13,7 +13,8 @@ for it in range(ncase):
         pkg.code_info(m, r, msg_len)
     except pkg.LvaError:
         continue
-    L = int(rng.choice([9, 12, 16, 24, 32, 48, 64])); md = int(rng.choice([20, 10])); margin = float(rng.choice([2.5, 3.0, 4.0]))
+    L = int(rng.choice([9, 12, 16, 24, 32, 36, 44, 48, 52, 60, 64]))   # (from 32 on, multiples of 4 with three planes: the record layout)
+    md = int(rng.choice([20, 10])); margin = float(rng.choice([2.5, 3.0, 4.0]))
     seed = int(rng.integers(1 << 30))
     reads = [synth.make_read(m, r, msg_len, seed + i, rc=bool(i & 1), margin=margin) for i in range(2)]
     with pkg.Decoder(m, r, msg_len, list_size=L, max_deviation=md, max_slots=2) as dec:
