@@ -193,6 +193,9 @@ static int upload_codes(lva_decoder* d) {
       r.vmask = c.vmask[p]; r.vval = c.vval[p]; r.vmask1 = c.vmask[q]; r.vval1 = c.vval[q];
       for (int nb = 0; nb < 4; ++nb) r.fpc[nb] = c.fpc[p][nb];
       r.np2 = p >= 2 ? dc[o].npair[p - 2] : 1u;
+      auto one_bit = [&](int64_t q) -> uint32_t { return q >= 1 && dc[o].ptype[q] == 0 ? 1u : 0u; };   // compact lists there (Geometry::cmp)
+      r.cmp3 = one_bit(p) | one_bit((int64_t)p - 1) << 1 | one_bit((int64_t)p - 2) << 2;
+      r.pad1 = 0;
       r.pred = dc[o].predtab[dc[o].ptype[p] & 3]; r.pred1 = dc[o].predtab[dc[o].ptype[q] & 3];
     }
   }
@@ -469,7 +472,7 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
     a.launch_no = d->launch_no; a.step_parity = d->launch_no & 1u;
     a.phase_aligned = d->kernel == 4 ? 1u : 0u;
     {
-      const int e = launch_prepare_step(a, d->d_steps, d->stream);
+      const int e = launch_prepare_step(a, d->d_codes, d->d_steps, d->stream);
       if (e) { g_hip_error = hipGetErrorString((hipError_t)e); return LVA_ERR_HIP; }
     }
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;

@@ -43,7 +43,9 @@ struct PosRec {                  // everything a workgroup needs to know about t
   uint32_t np2;                  // npair[pos-2] (1 when pos < 2)
   const uint16_t* pred;          // predtab[ptype[pos]]
   const uint16_t* pred1;         // predtab[ptype[pos-1]]
-  uint32_t pad1[2];
+  uint32_t cmp3;                 // compact-list flags (Geometry::cmp): bit 0 = position pos, bit 1 = pos-1, bit 2 = pos-2 is a one-bit
+                                 // position >= 1 (its lists are stored four per conv state)
+  uint32_t pad1;
 };
 static_assert(sizeof(PosRec) == 64, "PosRec is one 64-byte scalar load");
 
@@ -81,7 +83,11 @@ struct SlotStep {                // what one read slot does in one trellis-step 
   uint32_t flags;                // lazy mode (kernel 4): bit 0 = the row of position lo-1 in the previous buffer is stale (written
                                  // before step t-1); bit 1 = which message buffer the messages of its entries live in
   uint32_t pad;
+  uint32_t srccmp[2];            // Geometry::cmp: bit y = the SOURCE position lo + y - 1 of band position lo + y stores compact lists
+                                 // (a workgroup then stages 4 x L rows instead of 8 x L) -- known from the slot record alone, before
+                                 // anything else is loaded; band positions beyond 64 read the flag from the position record
 };
+static_assert(sizeof(SlotStep) == 48, "twelve words");
 
 struct StepArgs {
   const SlotDesc* slots;         // device
@@ -101,6 +107,11 @@ struct Geometry {                // strides in 32-bit words
   uint32_t N, L, W, F, R, P;
   uint32_t sBlk;                 // one (ring, crf, list entry) block = N*F
   uint32_t lazy;                 // kernel mode 4: messages are materialised every second time step (lva_kernels.hip, "lazy")
+  uint32_t cmp;                  // compact lists (lazy mode): at a one-bit position >= 1 a conv state has two COMPLEMENTARY bases
+                                 // ({A,T} or {C,G}: both generators tap the newest bit), so 4 of its 8 crf lists exist -- the list of
+                                 // crf state k is stored as list k >> 1 of the ring position (flip {A|C}, flip {T|G}, flop {A|C}, flop {T|G}).
+                                 // Readers stage 4 x L rows of such a source position, all of them data, instead of 8 x L rows of which
+                                 // half is never-written memory interleaved at conv-state granularity
   uint32_t rec;                  // big-list kernel, three message planes, L >= 32 and a multiple of 4: RECORD layout.  A (ring, crf) list is
                                  //   [conv N][entry L][8 words: score, fingerprint, message words 4-5, message words 0-3]
                                  // instead of L blocks of conv-fastest planes: the entries of one conv state's list are adjacent
@@ -113,7 +124,7 @@ inline Geometry make_geometry(uint32_t N, uint32_t L, uint32_t msg_bits, uint32_
   Geometry g;
   g.N = N; g.L = L; g.P = (msg_bits + 63) / 64; if (g.P == 0) g.P = 1;
   g.W = 2 * g.P; g.F = g.W + 2; g.R = R;
-  g.lazy = lazy; g.rec = (rec && !lazy && g.P == 3 && L >= 32 && L % 4 == 0) ? 1u : 0u;   // (below 32 entries the plane layout is faster: measured)
+  g.lazy = lazy; g.cmp = lazy ? 1u : 0u; g.rec = (rec && !lazy && g.P == 3 && L >= 32 && L % 4 == 0) ? 1u : 0u;   // (below 32 entries the plane layout is faster: measured)
   g.sBlk = N * g.F;
   // lazy mode: behind the L entry blocks of a (ring, crf) list, L back-pointer bytes per conv state ([conv][entry])
   g.sCrf = (uint64_t)g.sBlk * L + (lazy ? (uint64_t)N * L / 4 : 0); g.sRing = g.sCrf * 8;

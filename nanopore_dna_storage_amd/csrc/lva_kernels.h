@@ -15,7 +15,7 @@ bool fast_kernel_available(const Geometry& g);
 int launch_step_wave(const StepArgs& a, const Geometry& g, const DevCode* codes, uint32_t* trellis, void* stream);
 bool wave_kernel_available(const Geometry& g);
 // this launch's SlotStep records (a.steps), to be enqueued right before the step launch
-int launch_prepare_step(const StepArgs& a, SlotStep* steps, void* stream);
+int launch_prepare_step(const StepArgs& a, const DevCode* codes, SlotStep* steps, void* stream);
 // initial scores of a slot + its descriptor (the read enters the slot)
 int launch_init_slot(const Geometry& g, const DevCode* codes, uint32_t* trellis, uint32_t slot, const SlotDesc& desc,
                      SlotDesc* slots, void* stream);

@@ -77,7 +77,13 @@ struct Target {          // everything the merge of one target state needs
   uint32_t np_dst, np_src; // message planes in use at pos and at pos-1
   uint32_t okmask;       // bit i: list i exists (bit 0 = stay)
   uint32_t nlists;       // 8 for a flip target, 2 for a flop target
+  uint32_t csrc;         // 1: the source position stores compact lists (Geometry::cmp): crf state kk's list is list kk >> 1 there
 };
+
+// Compact lists (Geometry::cmp, lazy mode): is `pos` a one-bit position >= 1 (four lists per conv state: crf k -> list k >> 1)?
+__device__ __forceinline__ uint32_t compact_pos(const DevCode& cd, const Geometry& g, uint32_t pos) {
+  return (g.cmp && pos >= 1 && cd.ptype[pos] == 0) ? 1u : 0u;
+}
 
 // crf state feeding list i (i >= 1) of target k: flip targets take every other crf state in
 // ascending order, flop target X- only takes X+ (:878-885)
@@ -106,8 +112,9 @@ __device__ __forceinline__ bool resolve_target(const DevCode& cd, const Geometry
   if ((c & cd.vmask[pos]) != cd.vval[pos]) return false;               // :700
   tg->k = k; tg->c = c;
   tg->row = k >= 4 ? 4u : k;                                           // :582-587
-  tg->own = (uint32_t)(((uint64_t)(pos % g.R) * 8 + k) * g.sCrf);
+  tg->own = (uint32_t)(((uint64_t)(pos % g.R) * 8 + (k >> compact_pos(cd, g, pos))) * g.sCrf);
   tg->np_dst = cd.npair[pos];
+  tg->csrc = 0;
   const bool stay_ok = pos < ss.prev_hi;   // written at step t-1 (or initialised, t = 0)
   if (pos == 0) {
     tg->src = 0; tg->cp = 0; tg->shift = 0; tg->newbits = 0; tg->fpc = 0; tg->np_src = 1;
@@ -126,6 +133,7 @@ __device__ __forceinline__ bool resolve_target(const DevCode& cd, const Geometry
   tg->np_src = cd.npair[pos - 1];
   tg->cp = cp;
   tg->src = (uint32_t)((uint64_t)((pos - 1) % g.R) * 8 * g.sCrf);
+  tg->csrc = compact_pos(cd, g, pos - 1);
   const uint32_t reach = source_reach(cd, ss, pos, cp);
   uint32_t ok = stay_ok ? 1u : 0u;
   if (k < 4) {
@@ -157,13 +165,25 @@ __device__ __forceinline__ bool load_slot(const StepArgs& a, uint32_t z, SlotSte
 // The same with the whole record requested at once: the compiler otherwise sinks the loads of the fields behind the
 // early exits that test t and hi, and a workgroup then waits for three scalar loads one after the other.
 __device__ __forceinline__ bool load_slot_whole(const StepArgs& a, uint32_t z, SlotStep* ss) {
-  static_assert(sizeof(SlotStep) == 40, "ten words");
+  static_assert(sizeof(SlotStep) == 48, "twelve words; the first nine are read here (the L = 1 kernel has no compact lists)");
   const uint32_t* p = reinterpret_cast<const uint32_t*>(a.steps + z);
   uint32_t w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3], w4 = p[4], w5 = p[5], w6 = p[6], w7 = p[7], w8 = p[8];
   asm volatile("" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3), "+s"(w4), "+s"(w5), "+s"(w6), "+s"(w7), "+s"(w8));
   ss->post_row = reinterpret_cast<const float*>(((unsigned long long)w1 << 32) | w0);
   ss->slot = w2; ss->t = w3; ss->lo = w4; ss->hi = w5; ss->prev_hi = w6; ss->orient = w7; ss->flags = w8; ss->pad = 0;
+  ss->srccmp[0] = 0; ss->srccmp[1] = 0;
   return w3 != 0xFFFFFFFFu;
+}
+
+// Does the SOURCE position pos - 1 of band position index y store compact lists (Geometry::cmp)?  From the slot record for the
+// first 64 band positions (no further load in front of the staging requests), from the position record beyond (unbanded decodes).
+__device__ __forceinline__ uint32_t source_compact(const Geometry& g, const DevCode& cd, const SlotStep& ss, uint32_t y, uint32_t pos) {
+  if (!g.cmp) return 0u;
+  if (y < 64u) {
+    const unsigned long long mask = ((unsigned long long)ss.srccmp[1] << 32) | ss.srccmp[0];   // (no indexing: the record stays in registers)
+    return (uint32_t)(mask >> y) & 1u;
+  }
+  return (cd.rec[pos].cmp3 >> 1) & 1u;
 }
 
 // work-list item: (((slot << 8 | band position index) << 3 | crf) << m) | conv
@@ -889,11 +909,13 @@ __device__ __forceinline__ bool fast_output(const Geometry& g, const uint32_t* _
 // target must be redone by the exact path.
 // The merge proper: decides the new list (scores and fingerprints are stored as it goes) and reports where every accepted
 // entry came from (asrc) and which fingerprint matches still have to be verified on the full message (rej0 / rej1).
+// crow (uniform): 1 = the staged image has the 4 x LL rows of a compact source position (row of crf state kk = kk >> 1).
 template <int LL, int NL>
 __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur,
                                                 const uint2* s_src, const float* s_post, uint32_t k, uint32_t c,
                                                 uint32_t sc, uint32_t own, uint32_t okmask, uint32_t fpc,
-                                                unsigned long long* o_asrc, unsigned long long* o_rej0, uint32_t* o_lc) {
+                                                unsigned long long* o_asrc, unsigned long long* o_rej0, uint32_t* o_lc,
+                                                uint32_t crow = 0) {
   const float NEG = -INFINITY;
   const uint32_t sBlk = g.sBlk;
   const uint32_t row = k >= 4 ? 4u : k;
@@ -923,7 +945,7 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
 #pragma unroll
   for (int i = 1; i < NL; ++i) {
     const uint32_t kk = list_crf(k, i);
-    const uint2 v = s_src[(kk * LL) * TS + sc];
+    const uint2 v = s_src[((kk >> crow) * LL) * TS + sc];
     const bool ok = ((okmask >> i) & 1u) && u2f(v.x) != NEG;
     h[i] = ok ? u2f(v.x) + s_post[row * 8 + kk] : NEG;
     if (ok && !(h[i] > NEG)) why = 2;
@@ -963,7 +985,7 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
     const uint32_t j = (ptr >> (4 * sel)) & 15u;
     // source side, computed for every lane (a stay pop reads list 1's slot harmlessly)
     const uint32_t kk = list_crf(k, sel == 0 ? 1u : sel);
-    const uint32_t at = (mul24(kk, LL) + j) * TS + sc;
+    const uint32_t at = (mul24(kk >> crow, LL) + j) * TS + sc;
     const bool has_next = j + 1 < (uint32_t)LL;
     const uint32_t fp_src = s_src[at].y ^ fpc;
     const float raw1 = u2f(s_src[has_next ? at + TS : at].x);
@@ -1045,6 +1067,8 @@ struct TileTarget {
   uint32_t base, reach;          // the base the target ends in; crf states of the source conv state that are stored
   uint32_t pk1;                  // predecessor-table word of the source conv state at pos-1 (0 where reach did not need it)
 };
+// compact-list flags of a position record, masked by the geometry (bit 0: pos, bit 1: pos-1, bit 2: pos-2)
+__device__ __forceinline__ uint32_t cmp_bits(const Geometry& g, const PosRec& pr) { return g.cmp ? pr.cmp3 : 0u; }
 template <uint32_t TSx>
 __device__ __forceinline__ bool tile_target(const DevCode& cd, const Geometry& g, const SlotStep& ss, uint32_t pos,
                                             uint32_t tile, uint32_t tid, TileTarget* t) {
@@ -1085,7 +1109,7 @@ __device__ __forceinline__ bool tile_target(const DevCode& cd, const Geometry& g
   }
   const uint32_t k = base + 4 * role;
   t->k = k; t->base = base; t->reach = reach;
-  t->own = (uint32_t)(((uint64_t)(pos % g.R) * 8 + k) * g.sCrf);
+  t->own = (uint32_t)(((uint64_t)(pos % g.R) * 8 + (k >> (cmp_bits(g, pr) & 1u))) * g.sCrf);
   uint32_t ok = pos < ss.prev_hi ? 1u : 0u;
   if (role == 0) {
 #pragma unroll
@@ -1256,6 +1280,7 @@ struct LazyCtx {
   uint32_t sh_q, nb_q, pk1;      // the move into (pos-1, cp); predecessors of cp there (predtab nibbles)
   uint32_t np_p, np_p1, np_p2;   // message planes in use at pos, pos-1, pos-2
   uint32_t t, fb, stale_pos1, stale_mb;  // time step; message buffer of fresh step t-1 entries; sources at pos-1 stale? its buffer
+  uint32_t c1, c2;               // compact lists at pos-1 / at pos-2 (crf kk -> list kk >> 1); `own` already names the target's list
 };
 
 // byte index, inside a parity buffer, of the back-pointer byte of entry j of conv state `conv` of the list that starts at word
@@ -1283,7 +1308,7 @@ __device__ __forceinline__ bool lazy_locate(const LazyCtx& x, uint32_t i, uint32
   *s1 = 0; *n1 = 0;
   const bool stay = i == 0;
   if (x.t & 1u) {                                            // odd step: step t-1's entries carry their messages
-    const uint32_t lst = sel(stay, own, src + mul24(kk, x.sCrf));
+    const uint32_t lst = sel(stay, own, src + mul24(kk >> opqs(x.c1), x.sCrf));
     *ent = sel(lazy_mbuf(x, i) != 0, M1, M0) + lst + mul24(j, x.sBlk) + x.pw;
     *conv = sel(stay, c, cp); *np = sel(stay, np_p, np_p1); *s2 = sel(stay, 0u, sh_p);
     return true;
@@ -1296,7 +1321,8 @@ __device__ __forceinline__ bool lazy_locate(const LazyCtx& x, uint32_t i, uint32
   const uint32_t y1 = (x.pk1 >> (4 * (kk & 3u))) & 7u;
   const uint32_t cpp = ((cp << x.sh_q) | y1) & (x.N - 1u);
   const uint32_t crf1 = list_crf(kk, stay1 ? 1u : i1);       // crf of the second hop's source when it is a move
-  const uint32_t l_ss = own, l_sm = src + mul24(crf1, x.sCrf), l_ms = src + mul24(kk, x.sCrf), l_mm = src2 + mul24(crf1, x.sCrf);
+  const uint32_t c1 = opqs(x.c1), c2 = opqs(x.c2);
+  const uint32_t l_ss = own, l_sm = src + mul24(crf1 >> c1, x.sCrf), l_ms = src + mul24(kk >> c1, x.sCrf), l_mm = src2 + mul24(crf1 >> c2, x.sCrf);
   const uint32_t lst = sel(stay, sel(stay1, l_ss, l_sm), sel(stay1, l_ms, l_mm));
   *conv = sel(stay, sel(stay1, c, cp), sel(stay1, cp, cpp));
   *np = sel(stay, sel(stay1, np_p, np_p1), sel(stay1, np_p1, np_p2));
@@ -1337,6 +1363,7 @@ __device__ __forceinline__ void lazy_ctx(const DevCode& cd, const Geometry& g, c
   // (pk1_known >= 0: the caller's tile_target has read this word already -- wherever the target has a source list at all)
   x->pk1 = pk1_known >= 0 ? (uint32_t)pk1_known : (pos >= 2 && !(ss.t & 1u)) ? (uint32_t)LVA_GLOBAL(uint16_t, pr.pred1)[cp] : 0u;
   x->np_p = (pr.info >> 16) & 0xFFu; x->np_p1 = pr.info >> 24; x->np_p2 = pr.np2;
+  x->c1 = (cmp_bits(g, pr) >> 1) & 1u; x->c2 = (cmp_bits(g, pr) >> 2) & 1u;
   x->t = ss.t; x->fb = ((ss.t - 1u) >> 1) & 1u;
   x->stale_pos1 = (pos == ss.lo) && (ss.flags & 1u);
   x->stale_mb = (ss.flags >> 1) & 1u;
@@ -1353,7 +1380,7 @@ __device__ __forceinline__ bool lazy_output(const Geometry& g, const LazyCtx& x,
   // the candidate's own back-pointer byte: staged in LDS for source lists, prefetched for the stay list
   auto bp_of = [&](uint32_t i, uint32_t j) __attribute__((always_inline)) -> uint32_t {
     if (i == 0) return (uint32_t)(own_bp >> (8 * j)) & 0xFFu;
-    return s_bp[(list_crf(x.k, i) * TS + sc) * LL + j];
+    return s_bp[((list_crf(x.k, i) >> opqs(x.c1)) * TS + sc) * LL + j];
   };
   // the fingerprint match filed under entry l must be the same message as the entry's (mw): anchor steps, where the
   // entry's message is in registers anyway
@@ -1392,7 +1419,7 @@ __device__ __forceinline__ bool lazy_output(const Geometry& g, const LazyCtx& x,
           const uint32_t* Ms = opqs(x.stale_pos1) ? (opqs(x.stale_mb) ? opqs(x.M1) : opqs(x.M0)) : Mf;
           const uint32_t np_a = opqs(x.np_p), np_b = opqs(x.np_p1);
           load_msg<P>(Mf + x.own + mul24(s, x.sBlk) + x.pw, x.N, x.c, np_a, ma);
-          load_msg<P>(Ms + opqs(x.src) + mul24(list_crf(x.k, f6 >> 3), x.sCrf) + mul24(f6 & 7u, x.sBlk) + x.pw, x.N, x.cp, np_b, mb);
+          load_msg<P>(Ms + opqs(x.src) + mul24(list_crf(x.k, f6 >> 3) >> opqs(x.c1), x.sCrf) + mul24(f6 & 7u, x.sBlk) + x.pw, x.N, x.cp, np_b, mb);
           push_var<2 * P>(mb, opqs(x.sh_p), x.nb_p);
 #pragma unroll
           for (int w = 0; w < 2 * P; ++w) good &= (ma[w] == mb[w]);
@@ -1500,9 +1527,12 @@ __global__ __launch_bounds__(8 * TS, kLazyMinWaves) void lva_step_lazy(StepArgs 
     return;
   }
 
-  // ---- stage the (score, fingerprint) pairs of 64 source conv states (and, for an anchor step, their back-pointer bytes) ----
+  // ---- stage the (score, fingerprint) pairs of 64 source conv states (and, for an anchor step, their back-pointer bytes):
+  //      8 crf lists, or the 4 compact lists of a one-bit source position (all of them data) ----
   const uint32_t src = (uint32_t)((uint64_t)((pos - 1) % g.R) * 8 * g.sCrf);
-  for (uint32_t chunk = tid; chunk < 8u * LL * (TS / 2); chunk += 8u * TS) {
+  const uint32_t crow = source_compact(g, cd, ss, blockIdx.y, pos);
+  const uint32_t nrow = 8u >> crow;
+  for (uint32_t chunk = tid; chunk < nrow * LL * (TS / 2); chunk += 8u * TS) {
     const uint32_t rowi = chunk / (TS / 2), lane2 = chunk % (TS / 2);       // rowi = crf * LL + l
     const uint4 v = *reinterpret_cast<const uint4*>(prev + src + (uint64_t)(rowi / LL) * g.sCrf + (uint64_t)(rowi % LL) * g.sBlk +
                                                     2 * (tile * TS) + 4 * lane2);
@@ -1510,7 +1540,7 @@ __global__ __launch_bounds__(8 * TS, kLazyMinWaves) void lva_step_lazy(StepArgs 
   }
   if (anchor && ss.t != 0) {              // per crf: the L bytes of 64 conv states = TS*LL contiguous bytes
     constexpr uint32_t kW = TS * LL / 4;   // words per crf
-    for (uint32_t chunk = tid; chunk < 8u * kW; chunk += 8u * TS) {
+    for (uint32_t chunk = tid; chunk < nrow * kW; chunk += 8u * TS) {
       const uint32_t kk = chunk / kW, w = chunk % kW;
       const uint32_t v = prev[src + (uint64_t)kk * g.sCrf + (uint64_t)LL * g.sBlk + (tile * TS * LL) / 4 + w];
       *reinterpret_cast<uint32_t*>(&s_bp[kk * TS * LL + 4 * w]) = v;
@@ -1531,8 +1561,8 @@ __global__ __launch_bounds__(8 * TS, kLazyMinWaves) void lva_step_lazy(StepArgs 
   }
   unsigned long long asrc = 0, rej0 = 0;
   uint32_t lc = 0;
-  int why = t.k < 4 ? fast_merge_core<LL, 8>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &lc)
-                    : fast_merge_core<LL, 2>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &lc);
+  int why = t.k < 4 ? fast_merge_core<LL, 8>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &lc, crow)
+                    : fast_merge_core<LL, 2>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &lc, crow);
   if (!why) {
     LazyCtx x;
     lazy_ctx(cd, g, ss, slot_base, pos, t.c, t.cp, t.k, t.own, &x, ANCHOR ? (int)t.pk1 : 0);
@@ -1600,7 +1630,7 @@ __global__ __launch_bounds__(256) void lva_step_fixup_lazy(StepArgs args, Geomet
     {
       const uint32_t i = lane >> 3, j = lane & 7u;
       if (i < tg.nlists && ((tg.okmask >> i) & 1u) && j < L) {
-        const uint32_t lst = i == 0 ? tg.own : tg.src + list_crf(k, i) * sCrf;
+        const uint32_t lst = i == 0 ? tg.own : tg.src + (list_crf(k, i) >> tg.csrc) * sCrf;
         const uint2 v = *reinterpret_cast<const uint2*>(prev + lst + j * sBlk + 2 * (i == 0 ? tg.c : tg.cp));
         cs = u2f(v.x); cy = i != 0 ? v.y ^ tg.fpc : v.y;
         if (anchor && ss.t != 0) cb = x.bp_prev[bp_byte_index(g, lst, j, i == 0 ? tg.c : tg.cp)];
@@ -2270,19 +2300,23 @@ __global__ __launch_bounds__(8 * TSB) void lva_step_big_rec(StepArgs args, Geome
 // One thread per read slot: resolve descriptor -> time step -> band of this launch into the SlotStep record the
 // step kernels read (small trellises run hundreds of slots per launch, and every workgroup of a slot would otherwise
 // walk the same chain of dependent loads, cold, by itself).
-__global__ void lva_prepare_step(StepArgs a, SlotStep* __restrict__ steps) {
+__global__ void lva_prepare_step(StepArgs a, const DevCode* __restrict__ codes, SlotStep* __restrict__ steps) {
   const uint32_t z = blockIdx.x * blockDim.x + threadIdx.x;
   if (z >= a.nslots) return;
   const SlotDesc d = a.slots[z];
   const uint32_t t = a.launch_no - d.start;
   SlotStep ss;
   ss.post_row = nullptr; ss.slot = z; ss.t = 0xFFFFFFFFu; ss.lo = 0; ss.hi = 0; ss.prev_hi = 0; ss.orient = 0; ss.flags = 0; ss.pad = 0;
+  ss.srccmp[0] = 0; ss.srccmp[1] = 0;
   if (t < d.nblk) {
     const uint32_t b = d.band[t];
     ss.post_row = d.post + (size_t)t * 40;
     ss.t = t; ss.lo = b & 0xFFFFu; ss.hi = (b >> 16) & 0x3FFFu; ss.flags = b >> 30;
     ss.prev_hi = t ? (d.band[t - 1] >> 16) & 0x3FFFu : 1u;       // what step t-1 wrote (only position 0 is initialised at t = 0)
     ss.orient = d.orient;
+    const DevCode& cd = codes[d.orient];          // (the masks are only read where the geometry has compact lists)
+    for (uint32_t p = ss.lo < 2u ? 2u : ss.lo; p < ss.hi && p - ss.lo < 64u; ++p)
+      if (cd.ptype[p - 1] == 0) ss.srccmp[(p - ss.lo) >> 5] |= 1u << ((p - ss.lo) & 31u);
   }
   steps[z] = ss;
 }
@@ -2327,7 +2361,7 @@ __global__ void lva_gather_final(Geometry g, const DevCode* __restrict__ codes, 
       uint32_t w[2 + 8];
       w[0] = kNegInfBits;
       for (uint32_t f = 1; f < g.F; ++f) w[f] = 0;
-      const uint32_t own = (uint32_t)(((uint64_t)(pos % g.R) * 8 + k) * g.sCrf);
+      const uint32_t own = (uint32_t)(((uint64_t)(pos % g.R) * 8 + (k >> compact_pos(cd, g, pos))) * g.sCrf);
       if ((reach >> k) & 1u) {
         w[0] = buf[own + l * g.sBlk + 2 * c]; w[1] = buf[own + l * g.sBlk + 2 * c + 1];
         if (w[0] != kNegInfBits) {
@@ -2342,7 +2376,7 @@ __global__ void lva_gather_final(Geometry g, const DevCode* __restrict__ codes, 
             if (i != 0) {
               const uint32_t y = (pk >> (4 * (k & 3u))) & 7u;
               conv = ((c << sh) | y) & (cd.nconv - 1);
-              lst = (uint32_t)(((uint64_t)((pos - 1) % g.R) * 8 + list_crf(k, i)) * g.sCrf);
+              lst = (uint32_t)(((uint64_t)((pos - 1) % g.R) * 8 + (list_crf(k, i) >> compact_pos(cd, g, pos - 1))) * g.sCrf);
               np = cd.npair[pos - 1]; s1 = sh;
             }
             uint32_t carry = s1 ? nbp : 0u;
@@ -2507,9 +2541,9 @@ int launch_step_fast(const StepArgs& a, const Geometry& g, const DevCode* codes,
   return e;
 }
 
-int launch_prepare_step(const StepArgs& a, SlotStep* steps, void* stream) {
+int launch_prepare_step(const StepArgs& a, const DevCode* codes, SlotStep* steps, void* stream) {
   if (a.nslots == 0) return 0;
-  hipLaunchKernelGGL(lva_prepare_step, dim3((a.nslots + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, steps);
+  hipLaunchKernelGGL(lva_prepare_step, dim3((a.nslots + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, codes, steps);
   return (int)hipGetLastError();
 }
 
