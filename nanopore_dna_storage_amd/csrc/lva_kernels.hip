@@ -165,13 +165,13 @@ __device__ __forceinline__ bool load_slot(const StepArgs& a, uint32_t z, SlotSte
 // The same with the whole record requested at once: the compiler otherwise sinks the loads of the fields behind the
 // early exits that test t and hi, and a workgroup then waits for three scalar loads one after the other.
 __device__ __forceinline__ bool load_slot_whole(const StepArgs& a, uint32_t z, SlotStep* ss) {
-  static_assert(sizeof(SlotStep) == 48, "twelve words; the first nine are read here (the L = 1 kernel has no compact lists)");
+  static_assert(sizeof(SlotStep) == 48, "twelve words");
   const uint32_t* p = reinterpret_cast<const uint32_t*>(a.steps + z);
-  uint32_t w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3], w4 = p[4], w5 = p[5], w6 = p[6], w7 = p[7], w8 = p[8];
-  asm volatile("" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3), "+s"(w4), "+s"(w5), "+s"(w6), "+s"(w7), "+s"(w8));
+  uint32_t w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3], w4 = p[4], w5 = p[5], w6 = p[6], w7 = p[7], w8 = p[8], w10 = p[10], w11 = p[11];
+  asm volatile("" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3), "+s"(w4), "+s"(w5), "+s"(w6), "+s"(w7), "+s"(w8), "+s"(w10), "+s"(w11));
   ss->post_row = reinterpret_cast<const float*>(((unsigned long long)w1 << 32) | w0);
   ss->slot = w2; ss->t = w3; ss->lo = w4; ss->hi = w5; ss->prev_hi = w6; ss->orient = w7; ss->flags = w8; ss->pad = 0;
-  ss->srccmp[0] = 0; ss->srccmp[1] = 0;
+  ss->srccmp[0] = w10; ss->srccmp[1] = w11;
   return w3 != 0xFFFFFFFFu;
 }
 
@@ -1066,6 +1066,7 @@ struct TileTarget {
   uint32_t own;                  // word offset of block (ring(pos), k, l=0)
   uint32_t base, reach;          // the base the target ends in; crf states of the source conv state that are stored
   uint32_t pk1;                  // predecessor-table word of the source conv state at pos-1 (0 where reach did not need it)
+  uint32_t c0;                   // 1: pos stores compact lists (crf k -> list k >> 1); `own` already names the target's list
 };
 // compact-list flags of a position record, masked by the geometry (bit 0: pos, bit 1: pos-1, bit 2: pos-2)
 __device__ __forceinline__ uint32_t cmp_bits(const Geometry& g, const PosRec& pr) { return g.cmp ? pr.cmp3 : 0u; }
@@ -1109,7 +1110,8 @@ __device__ __forceinline__ bool tile_target(const DevCode& cd, const Geometry& g
   }
   const uint32_t k = base + 4 * role;
   t->k = k; t->base = base; t->reach = reach;
-  t->own = (uint32_t)(((uint64_t)(pos % g.R) * 8 + (k >> (cmp_bits(g, pr) & 1u))) * g.sCrf);
+  t->c0 = cmp_bits(g, pr) & 1u;
+  t->own = (uint32_t)(((uint64_t)(pos % g.R) * 8 + (k >> t->c0)) * g.sCrf);
   uint32_t ok = pos < ss.prev_hi ? 1u : 0u;
   if (role == 0) {
 #pragma unroll
@@ -1128,7 +1130,7 @@ __device__ __forceinline__ bool tile_target(const DevCode& cd, const Geometry& g
 template <int P>
 __device__ __forceinline__ void acs_pair(const Geometry& g, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur,
                                          const uint2* s_src, const float* s_post, uint32_t src, bool v0, const TileTarget& t0,
-                                         bool v1, const TileTarget& t1, lva_u32x2 s0, lva_u32x2 s1) {
+                                         bool v1, const TileTarget& t1, lva_u32x2 s0, lva_u32x2 s1, uint32_t crow) {
   const float NEG = -INFINITY;
   const uint32_t sCrf = g.sBlk, pw = 2 * g.N;
   const uint32_t own0 = t0.own + 2 * t0.c, own1 = t1.own + 2 * t1.c;
@@ -1140,7 +1142,7 @@ __device__ __forceinline__ void acs_pair(const Geometry& g, const uint32_t* __re
 #pragma unroll
     for (int i = 1; i < 8; ++i) {
       if ((t0.ok >> i) & 1u) {
-        const uint2 v = s_src[list_crf(k, i) * TS + t0.sc];
+        const uint2 v = s_src[(list_crf(k, i) >> crow) * TS + t0.sc];
         const float c = u2f(v.x) + s_post[k * 8 + list_crf(k, i)];
         if (c > best0) { best0 = c; bi0 = i; bh0 = v.y ^ t0.fpc; }
       }
@@ -1151,15 +1153,15 @@ __device__ __forceinline__ void acs_pair(const Geometry& g, const uint32_t* __re
     const float s = u2f(s1.x) + s_post[4 * 8 + k];
     if ((t1.ok & 1u) && s > best1) { best1 = s; bh1 = s1.y; }
     if ((t1.ok >> 1) & 1u) {
-      const uint2 v = s_src[list_crf(k, 1) * TS + t1.sc];
+      const uint2 v = s_src[(list_crf(k, 1) >> crow) * TS + t1.sc];
       const float c = u2f(v.x) + s_post[4 * 8 + list_crf(k, 1)];
       if (c > best1) { best1 = c; bi1 = 1; bh1 = v.y ^ t1.fpc; }
     }
   }
   const bool w0 = v0 && best0 != NEG, w1 = v1 && best1 != NEG;
   uint32_t m0[2 * P], m1[2 * P];
-  const uint32_t* e0 = prev + (bi0 == 0 ? t0.own : src + mul24(list_crf(t0.k, bi0), sCrf)) + pw;
-  const uint32_t* e1 = prev + (bi1 == 0 ? t1.own : src + mul24(list_crf(t1.k, bi1), sCrf)) + pw;
+  const uint32_t* e0 = prev + (bi0 == 0 ? t0.own : src + mul24(list_crf(t0.k, bi0) >> crow, sCrf)) + pw;
+  const uint32_t* e1 = prev + (bi1 == 0 ? t1.own : src + mul24(list_crf(t1.k, bi1) >> crow, sCrf)) + pw;
   const uint32_t c0 = bi0 == 0 ? t0.c : t0.cp, c1 = bi1 == 0 ? t1.c : t1.cp;
   const uint32_t npd = opqs(t0.np_dst), nps = opqs(t0.np_src);     // (uniform over the workgroup)
   if (npd == nps) {     // the plane count does not change at this position (all but two or three positions): ONE uniform
@@ -1777,13 +1779,15 @@ __global__ __launch_bounds__(4 * TS) void lva_step_acs(StepArgs args, Geometry g
   // the tables of this thread's targets and -- behind those -- their stay entries.  What is left of the chain of round trips:
   // (slot record) -> (staging | tables -> stay entries) -> barrier -> winners -> their messages -> stores.
   const uint32_t rowi = tid / (TS / 2), lane2 = tid % (TS / 2);
-  const lva_u32x4 sv = *LVA_GLOBAL(lva_u32x4, prev + src + (uint64_t)rowi * g.sBlk + 2 * (tile * TS) + 4 * lane2);
+  const uint32_t crow = source_compact(g, cd, ss, blockIdx.y, pos);      // 4 rows instead of 8: a one-bit source position
+  lva_u32x4 sv = {kNegInfBits, 0u, kNegInfBits, 0u};
+  if (rowi < (8u >> crow)) sv = *LVA_GLOBAL(lva_u32x4, prev + src + (uint64_t)rowi * g.sBlk + 2 * (tile * TS) + 4 * lane2);
   float pv = 0.0f;
   if (tid < 40) pv = LVA_GLOBAL(float, ss.post_row)[tid];
   TileTarget t0;
   const bool valid = tile_target<TS>(cd, g, ss, pos, tile, tid, &t0);   // role 0: the flip target of (base, conv)
   TileTarget t1 = t0;                                                    // role 1: the flop target of the same (base, conv)
-  t1.k = t0.base + 4; t1.own = t0.own + 4u * (uint32_t)g.sCrf;
+  t1.k = t0.base + 4; t1.own = t0.own + (4u >> t0.c0) * (uint32_t)g.sCrf;     // (compact lists: flop list = flip list + 2)
   t1.ok = (t0.ok & 1u) | (((t0.reach >> t0.base) & 1u) << 1);
   lva_u32x2 s0 = {kNegInfBits, 0u}, s1 = {kNegInfBits, 0u};
   if (valid && (t0.ok & 1u)) {           // (the stay bit is the same for both)
@@ -1794,7 +1798,7 @@ __global__ __launch_bounds__(4 * TS) void lva_step_acs(StepArgs args, Geometry g
   if (tid < 40) s_post[tid] = pv;
   __syncthreads();
   if (!valid) return;
-  acs_pair<P>(g, prev, cur, s_src, s_post, src, true, t0, true, t1, s0, s1);
+  acs_pair<P>(g, prev, cur, s_src, s_post, src, true, t0, true, t1, s0, s1, crow);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2405,7 +2409,7 @@ __global__ void lva_gather_final(Geometry g, const DevCode* __restrict__ codes, 
     const uint32_t f = i % g.F, l = (i / g.F) % g.L, k = i / (g.F * g.L);
     uint32_t v = f == 0 ? kNegInfBits : 0u;
     if (((reach >> k) & 1u) && (f < 2 || ((f - 2) >> 1) < np)) {
-      const uint32_t lst = (uint32_t)(((uint64_t)(pos % g.R) * 8 + k) * g.sCrf);
+      const uint32_t lst = (uint32_t)(((uint64_t)(pos % g.R) * 8 + (k >> compact_pos(cd, g, pos))) * g.sCrf);
       v = f < 2 ? buf[rec_sh(g, lst, c, l) + f] : entry_word(g, buf, lst, c, l, f - 2, np);
     }
     out[i] = v;
