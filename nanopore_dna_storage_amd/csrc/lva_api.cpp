@@ -64,6 +64,7 @@ struct lva_decoder {
   uint32_t work_cap = 1u << 20;
   int kernel = 1;              // 1 = exact, 2 = fast + exact fix-up
   uint32_t launch_no = 0;      // trellis-step launches since creation (the slots' clock)
+  uint32_t full_lo = 1, full_hi = 0;   // positions at which every 64-source tile has a valid target (StepArgs::full_lo/hi)
   int launch_events = 0;       // lva_decoder_set_launch_events
   std::vector<hipEvent_t> ev_pool;
   lva_profile prof{};
@@ -222,6 +223,28 @@ int lva_decoder_create(const lva_config* cfg, lva_decoder** out) {
   if (c.msg_len > 255 || c.msg_len + (uint32_t)c.mem_conv > 256) { delete d; return LVA_ERR_MSG_TOO_LONG; }
   if ((uint64_t)c.npos * kCrf * c.nconv >= ((uint64_t)1 << 32)) { delete d; return LVA_ERR_TOO_MANY_STATES; }
   d->max_dev = cfg->max_deviation == LVA_MAX_DEVIATION_DEFAULT ? c.msg_len + (uint32_t)c.mem_conv + 1 : cfg->max_deviation;
+  {
+    // Positions at which every tile of 64 source conv states feeds at least one valid target conv state, in both orientations:
+    // the longest run [full_lo, full_hi].  A target conv state of tile x at position p is  x*Tn + low + leg*(N >> sh)  (low < Tn =
+    // 64 >> sh, leg < 2^sh): its middle bits are the tile's, so the tile has a valid target iff those bits agree with the mask.
+    const uint32_t N = c.nconv;
+    std::vector<uint8_t> full(c.npos, 0);
+    for (uint32_t p = 1; p < c.npos; ++p) {
+      bool ok = N >= 64;
+      for (int o = 0; o < 2 && ok; ++o) {
+        const Code& co = d->code[o];
+        const uint32_t sh = co.ptype[p] == 0 ? 1u : 2u, Tn = 64u >> sh;
+        const uint32_t mid = (N - 1) & ~(Tn - 1) & ~(((1u << sh) - 1u) << ((uint32_t)co.mem_conv - sh));
+        for (uint32_t x = 0; x < N / 64 && ok; ++x) ok = ((x * Tn) & co.vmask[p] & mid) == (co.vval[p] & mid);
+      }
+      full[p] = ok ? 1 : 0;
+    }
+    uint32_t best = 0, run = 0;
+    for (uint32_t p = 1; p < c.npos; ++p) {
+      run = full[p] ? run + 1 : 0;
+      if (run > best) { best = run; d->full_hi = p; d->full_lo = p + 1 - run; }
+    }
+  }
   // kernel mode 4 ("lazy", list sizes 2, 4, 8): messages are materialised every second time step and carried as one-byte
   // back-pointers in between; two-hop chains reach one position further below the band, hence one more ring position
   // Default (kernel 0) for list sizes 2 / 4 / 8 (m = 11 L = 8: +5 % over kernel 2, m = 8: +9 %; m = 14 with four message planes: +8 %
@@ -474,6 +497,7 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
     a.slots = d->d_slots; a.steps = d->d_steps; a.nslots = (uint32_t)slot.size(); a.band_max = band_max;
     a.launch_no = d->launch_no; a.step_parity = d->launch_no & 1u;
     a.phase_aligned = d->kernel == 4 ? 1u : 0u;
+    a.full_lo = d->full_lo; a.full_hi = d->full_hi; a.pad = 0;
     {
       const int e = launch_prepare_step(a, d->d_codes, d->d_steps, d->stream);
       if (e) { g_hip_error = hipGetErrorString((hipError_t)e); return LVA_ERR_HIP; }

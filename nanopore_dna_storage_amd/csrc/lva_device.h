@@ -100,6 +100,9 @@ struct StepArgs {
   uint32_t launch_no;
   uint32_t phase_aligned;        // lazy mode: every slot's time step has the parity of launch_no (the host starts reads on even
                                  // launches only), so only the lva_step_lazy instance of that parity is launched
+  uint32_t full_lo, full_hi;     // positions full_lo .. full_hi (both orientations): every source tile feeds at least one VALID target
+                                 // conv state (:700).  Outside -- the first and last few positions, where most of the register is pinned
+                                 // to the initial / final state -- a workgroup tests its tile before it stages anything (tile_has_target)
   uint32_t pad;
 };
 
