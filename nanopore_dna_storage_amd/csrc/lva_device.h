@@ -111,7 +111,7 @@ struct Geometry {                // strides in 32-bit words
   uint32_t sBlk;                 // one (ring, crf, list entry) block = N*F
   uint32_t lazy;                 // kernel mode 4: messages are materialised every second time step (lva_kernels.hip, "lazy")
   uint32_t cmp;                  // compact lists (lazy mode, and the L = 1 kernel): at a one-bit position >= 1 a conv state has two COMPLEMENTARY bases
-                                 // ({A,T} or {C,G}: both generators tap the newest bit), so 4 of its 8 crf lists exist -- the list of
+                                 // ({A,T} or {C,G}: its two predecessors differ in the register bit the step shifts out, which both generators tap), so 4 of its 8 crf lists exist -- the list of
                                  // crf state k is stored as list k >> 1 of the ring position (flip {A|C}, flip {T|G}, flop {A|C}, flop {T|G}).
                                  // Readers stage 4 x L rows of such a source position, all of them data, instead of 8 x L rows of which
                                  // half is never-written memory interleaved at conv-state granularity

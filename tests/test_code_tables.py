@@ -80,3 +80,27 @@ def test_algorithmic_bytes_match_survey():
     assert abs(b / 1e9 - 111.9) < 0.6
     b = pkg.algorithmic_bytes(6, 1, 180, 823, 1, 20)
     assert abs(b / 1e9 - 0.446) < 0.01
+
+
+def test_one_bit_positions_have_complementary_base_pairs():
+    """What the compact lists of the kernels rest on (lva_device.h Geometry::cmp): at a one-bit position (block type 0) the bases a
+    valid conv state can end in are a complementary pair, {A,T} or {C,G} -- the two predecessors of a target differ in the register
+    bit the step shifts out, which both generators tap (viterbi_convolutional_code.cpp:269-289, :890-904) -- so crf state k's list
+    can be stored as list k >> 1.  Every supported memory, both orientations, a sync marker included."""
+    import nanopore_dna_storage_amd as pkg
+    seen = 0
+    for m, r, ml, kw in [(6, 1, 60, {}), (6, 3, 60, {}), (6, 5, 180, {}), (8, 1, 100, {}), (8, 2, 100, {}), (8, 3, 164, {}), (8, 4, 100, {}),
+                         (8, 5, 180, {}), (11, 1, 40, {}), (11, 2, 61, {}), (11, 5, 180, {}), (14, 1, 20, {}), (14, 7, 180, {}),
+                         (6, 1, 60, dict(sync_marker="110", sync_period=9))]:
+        for rc in (False, True):
+            t = pkg.code_tables(m, r, ml, rc=rc, **kw)
+            c = np.arange(1 << m)
+            pk = t["predtab"][0][:1 << m].astype(np.uint32)
+            has = ((pk >> 3) & 1) | (((pk >> 7) & 1) << 1) | (((pk >> 11) & 1) << 2) | (((pk >> 15) & 1) << 3)
+            for pos in range(1, len(t["ptype"])):
+                if t["ptype"][pos] != 0:
+                    continue
+                h = has[(c & t["vmask"][pos]) == t["vval"][pos]]
+                assert np.all((h == 0b1001) | (h == 0b0110)), (m, r, ml, rc, pos)
+                seen += len(h)
+    assert seen > 100000
