@@ -252,9 +252,10 @@ def main():
         use_events = acc["tl"] > 0
         dom_ms = acc["dom_ms"] if use_events else acc["span_ms"]
         achieved = (acc["alg"] / 1e9) / (dom_ms / 1e3) if dom_ms > 0 else 0.0
-        kname = {2: "lva_step_fast<%d,P>" % a.list_size if a.list_size in (2, 4, 8) else ("lva_step_acs<P>" if a.list_size == 1 else "lva_step_big<LL,P>"),
-                 4: "lva_step_lazy<%d,P,true> + lva_step_lazy<%d,P,false> (the anchor-step and the odd-step instance: every launch runs both, "
-                    "each serves the read slots at its kind of time step)" % (a.list_size, a.list_size),
+        kname = {2: "lva_step_fast<%d,P>" % a.list_size if a.list_size in (2, 4, 8) else ("lva_step_acs<P>" if a.list_size == 1 else "lva_step_big<LL,P> / lva_step_big_rec<LL>"),
+                 4: "lva_step_lazy<%d,P,true> | lva_step_lazy<%d,P,false> (the anchor-step and the odd-step instance: the slots are "
+                    "phase-aligned, so even launches run the first over all slots and odd launches the second; avg_launch_ms is the "
+                    "mean over both kinds of launch)" % (a.list_size, a.list_size),
                  3: "lva_step_wave", 1: "lva_step_exact"}.get(prof["kernel"], "?")
         # HBM bytes per launch from this round's PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
         # passes, scripts/pmc_mem.sh), per read-step, scaled to this run's mean number of active slots per launch
