@@ -21,7 +21,13 @@
 //     positions are stored instead of the reference's nstate_pos.
 //   * states the reference leaves at -inf forever (invalid conv states :700, and (conv,crf)
 //     pairs whose only predecessor is "stay") are neither stored nor read: readers test the
-//     same predicates instead.
+//     same predicates instead.  The same holds for positions a path cannot have reached yet
+//     (> t + 1 after step t) and for positions that cannot reach the final one any more
+//     (< npos - nblk + t): the host clips the band table of every step to that range
+//     (lva_api.cpp decode_impl), and "outside the band" already reads as -inf / is never used.
+//   * variants of this layout, selected per decoder (Geometry below): compact lists at one-bit
+//     positions (cmp: 4 lists per ring position there), back-pointer bytes behind every list
+//     (lazy), and [conv][entry] records instead of planes for long lists (rec).
 //
 // Message fingerprint: XOR over the set message bits of a fixed pseudo-random 32-bit word per
 // bit index (index = order of consumption).  Appending bits at a step XORs a constant that
