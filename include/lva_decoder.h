@@ -111,6 +111,15 @@ int lva_code_tables(int32_t mem_conv, int32_t rate, uint32_t msg_len, int32_t rc
                     const char *sync_marker, uint32_t sync_period, uint32_t *pos2msg, uint8_t *ptype,
                     uint32_t *vmask, uint32_t *vval, uint16_t *predtab);
 
+/* The band [lo, hi) of every time step of a read of nblk blocks, for inspection/tests (each output may be NULL, 2*nblk words):
+ *   reference_lo_hi  as the reference computes it (:677-679, with the fused multiply-subtract of its build);
+ *   working_lo_hi    what the kernels work on: the same without positions a path cannot have reached yet (> t + 1) and
+ *                    positions that cannot reach the final one any more (< nstate_pos - nblk + t) -- their lists never
+ *                    reach the output, so they are neither written nor read. */
+int lva_band_table(int32_t mem_conv, int32_t rate, uint32_t msg_len, int32_t rc, const char *sync_marker,
+                   uint32_t sync_period, uint32_t nblk, uint32_t max_deviation, uint32_t *reference_lo_hi,
+                   uint32_t *working_lo_hi);
+
 /* `-m encode` (:215-225): conv_encode (:450-499) + 2-bit base packing (:540-551).
  * msgs: n_msgs*msg_len bytes of 0/1.  out_bases: n_msgs*oligo_len bytes, values 0..3 = A,C,G,T. */
 int lva_encode(int32_t mem_conv, int32_t rate, uint32_t msg_len, const uint8_t *msgs, int32_t n_msgs,

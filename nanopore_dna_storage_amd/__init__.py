@@ -7,5 +7,5 @@ hand-written HIP kernels for gfx950.  There is no CPU fallback: decoding raises 
 HIP library or a GPU is missing.
 """
 from ._lib import LvaError, library_path, load_library  # noqa: F401
-from .decoder import (CodeInfo, Decoder, algorithmic_bytes, code_info, code_tables, encode,  # noqa: F401
+from .decoder import (CodeInfo, Decoder, algorithmic_bytes, band_table, code_info, code_tables, encode,  # noqa: F401
                       bases_to_str, str_to_bits)

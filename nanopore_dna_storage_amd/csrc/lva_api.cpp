@@ -152,6 +152,38 @@ int lva_encode(int32_t mem_conv, int32_t rate, uint32_t msg_len, const uint8_t* 
   return LVA_OK;
 }
 
+// The band of time step t the kernels work on: the reference's (:677-679, Code::band) without the positions whose lists
+// cannot matter.
+//  * A path advances at most one position per time step, so after step t only positions <= t + 1 hold a finite score: the
+//    reference writes -inf lists above (:799), the kernels neither write nor read them -- the band ends at t + 2 for them, and
+//    "beyond the previous band end" already reads as -inf (the upper band edge).  3.8 % of a read's (step, position) pairs.
+//  * A state at position p after step t can still reach the final position only if p >= npos - nblk + t; states below feed
+//    nothing that the final selection (:806-824) reads -- a state's predecessors lie one position lower or one step earlier, so
+//    states that matter depend on states that matter only -- and are neither written nor read: the band starts there.  1.2 %.
+// (tests/test_host_logic.py checks both against a reachability computation on the reference's band.)
+static void working_band(const Code& c, uint32_t t, uint32_t nblk, uint32_t max_dev, uint32_t* lo_out, uint32_t* hi_out) {
+  uint32_t lo, hi;
+  c.band(t, nblk, max_dev, &lo, &hi);
+  hi = std::min<uint32_t>(hi, t + 2);
+  const int64_t alive = (int64_t)c.npos - (int64_t)nblk + (int64_t)t;
+  if (alive > (int64_t)lo) lo = (uint32_t)std::min<int64_t>(alive, hi);
+  *lo_out = lo; *hi_out = hi;
+}
+
+int lva_band_table(int32_t mem_conv, int32_t rate, uint32_t msg_len, int32_t rc, const char* sync_marker, uint32_t sync_period,
+                   uint32_t nblk, uint32_t max_deviation, uint32_t* reference_lo_hi, uint32_t* working_lo_hi) {
+  Code c;
+  const int st = build_code(&c, mem_conv, rate, msg_len, rc, sync_marker, sync_period);
+  if (st != LVA_OK) return st;
+  if (max_deviation == LVA_MAX_DEVIATION_DEFAULT) max_deviation = msg_len + (uint32_t)mem_conv + 1;
+  for (uint32_t t = 0; t < nblk; ++t) {
+    uint32_t lo, hi;
+    if (reference_lo_hi) { c.band(t, nblk, max_deviation, &lo, &hi); reference_lo_hi[2 * t] = lo; reference_lo_hi[2 * t + 1] = hi; }
+    if (working_lo_hi) { working_band(c, t, nblk, max_deviation, &lo, &hi); working_lo_hi[2 * t] = lo; working_lo_hi[2 * t + 1] = hi; }
+  }
+  return LVA_OK;
+}
+
 int lva_algorithmic_bytes(int32_t mem_conv, int32_t rate, uint32_t msg_len, int32_t rc, const char* sync_marker,
                           uint32_t sync_period, uint32_t nblk, uint32_t list_size, uint32_t max_deviation,
                           double* out) {
@@ -426,19 +458,7 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
       if (d->g.lazy) { last_w[0].assign(c.npos + 1, -1); last_w[1].assign(c.npos + 1, -1); if (c.npos) last_w[1][0] = -1; }
       for (uint32_t t = 0; t < nb; ++t) {
         uint32_t lo, hi;
-        c.band(t, nb, d->max_dev, &lo, &hi);
-        // A path advances at most one position per time step, so after step t only positions <= t + 1 hold a finite score: the
-        // reference writes -inf lists above (:799), the kernels neither write nor read them -- the band ends at t + 2 for them,
-        // and "beyond the previous band end" already reads as -inf (the upper band edge).  3.8 % of a read's (step, position) pairs.
-        hi = std::min<uint32_t>(hi, t + 2);
-        // The other end: a state at position p after step t can still reach the final position only if p >= npos - nb + t (one
-        // position per step at most); states below feed nothing that the final selection (:806-824) reads -- a state's
-        // predecessors lie one position lower or one step earlier, so states that matter depend on states that matter only --
-        // and are neither written nor read: the band starts there.  1.2 % of a read's (step, position) pairs.
-        {
-          const int64_t alive = (int64_t)c.npos - (int64_t)nb + (int64_t)t;
-          if (alive > (int64_t)lo) lo = (uint32_t)std::min<int64_t>(alive, hi);
-        }
+        working_band(c, t, nb, d->max_dev, &lo, &hi);
         uint32_t w = lo | (hi << 16);
         if (d->g.lazy) {
           const int pc = (int)((t + 1) & 1u);                // parity class of the steps that wrote step t's "prev" buffer: t-1

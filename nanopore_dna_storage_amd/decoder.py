@@ -62,6 +62,20 @@ def code_tables(mem_conv, rate, msg_len, rc=False, sync_marker="", sync_period=0
     return dict(pos2msg=pos2msg, ptype=ptype, vmask=vmask, vval=vval, predtab=predtab)
 
 
+def band_table(mem_conv, rate, msg_len, nblk, max_deviation=None, rc=False, sync_marker="", sync_period=0):
+    """-> (reference, working): int arrays [nblk, 2] of [lo, hi) per time step -- the reference's band (:677-679) and the band the
+    kernels work on (without positions whose lists cannot reach the output; include/lva_decoder.h lva_band_table)."""
+    L = load_library()
+    ref = np.zeros((nblk, 2), np.uint32)
+    work = np.zeros((nblk, 2), np.uint32)
+    md = 0xFFFFFFFF if max_deviation is None else int(max_deviation)
+    st = L.lva_band_table(mem_conv, rate, msg_len, int(bool(rc)), _sm(sync_marker), sync_period, int(nblk), md,
+                          ref.ctypes.data, work.ctypes.data)
+    if st != 0:
+        raise LvaError(st)
+    return ref.astype(np.int64), work.astype(np.int64)
+
+
 def encode(mem_conv, rate, msg_len, msgs):
     """msgs: array [n, msg_len] (or [msg_len]) of 0/1 -> uint8 array [n, oligo_len] of 0..3 (A,C,G,T)."""
     msgs = np.ascontiguousarray(msgs, dtype=np.uint8)

@@ -243,3 +243,39 @@ def test_list_files_are_written_atomically(tmp_path):
     args = gdl.build_parser().parse_args(["--post_manifest", "m", "--out_prefix", "o", "--info_file", "i", "--mem_conv", "6", "--msg_len", "60",
                                           "--rate_conv", "1", "--list_size", "4"])
     assert args.chunk == 4096 and args.max_deviation == 20 and args.gpus == 1
+
+
+@pytest.mark.parametrize("m,r,msg_len,md,rc", [(6, 1, 60, 20, False), (6, 1, 24, 3, True), (8, 3, 164, 20, False), (11, 5, 180, 20, True),
+                                               (8, 3, 44, 1, False), (6, 5, 180, None, False), (14, 7, 180, 5, False)])
+def test_working_band_keeps_every_state_that_can_matter(oracle, m, r, msg_len, md, rc):
+    """The kernels work on the reference's band (:677-679) minus the positions a path cannot have reached yet (> t + 1) and the
+    positions that cannot reach the final one any more (lva_api.cpp working_band).  Property: the reference band is reproduced
+    exactly (oracle), the working band lies inside it, and every (step, position) cell that lies on SOME monotone path
+    (stay or +1 position per step, every cell inside the reference band) from (step 0, position <= 1) to (last step, last
+    position) is still inside the working band -- for several read lengths, incl. the shortest the reference accepts."""
+    info = pkg.code_info(m, r, msg_len, rc)
+    npos = info.nstate_pos
+    code = oracle.OracleCode(m, r, msg_len, rc=rc)
+    for nblk in (npos + 1, npos + 2, 2 * npos + 3, int(4.4 * npos), int(4.4 * npos) + 1):
+        ref, work = pkg.band_table(m, r, msg_len, nblk, md, rc=rc)
+        want = np.array([code.band(t, nblk, md if md is not None else msg_len + m + 1) for t in range(nblk)], dtype=np.int64)
+        assert np.array_equal(ref, want), "reference band differs from the oracle's"
+        assert np.all(ref[:, 0] <= work[:, 0]) and np.all(work[:, 1] <= ref[:, 1]) and np.all(work[:, 0] <= work[:, 1])
+        # forward: cells reachable from the start inside the reference band; backward: cells that reach the final cell
+        inb = np.zeros((nblk, npos), bool)
+        for t in range(nblk):
+            inb[t, ref[t, 0]:ref[t, 1]] = True
+        fwd = np.zeros((nblk, npos), bool)
+        fwd[0, :2] = inb[0, :2]                                   # after step 0: position 0 (stay) and position 1 (one move)
+        for t in range(1, nblk):
+            fwd[t] = inb[t] & (fwd[t - 1] | np.concatenate([[False], fwd[t - 1][:-1]]))
+        bwd = np.zeros((nblk, npos), bool)
+        bwd[nblk - 1, npos - 1] = inb[nblk - 1, npos - 1]
+        for t in range(nblk - 2, -1, -1):
+            bwd[t] = inb[t] & (bwd[t + 1] | np.concatenate([bwd[t + 1][1:], [False]]))
+        need = fwd & bwd
+        for t in range(nblk):
+            p = np.nonzero(need[t])[0]
+            assert p.size == 0 or (work[t, 0] <= p.min() and p.max() < work[t, 1]), (nblk, t, p.min(), p.max(), work[t])
+        # and it really is smaller where it can be
+        assert work[0, 1] <= 2 and work[nblk - 1, 0] >= min(npos - 1, ref[nblk - 1, 1])
