@@ -283,6 +283,10 @@ def main():
             "kernel": kname + " (one trellis step of every active read slot)",
             "basis": ("algorithmic bytes / sum of per-launch HIP-event times of the dominant kernel alone" if use_events
                       else "algorithmic bytes / HIP-event span first..last step launch"),
+            "algorithmic_bytes_definition": "SURVEY 8(d): sum over time steps of the structurally reachable in-band states of the "
+                                            "REFERENCE's band; since round 4 the kernels skip the cells of that band whose lists cannot reach the "
+                                            "output (positions > t + 1 and < nstate_pos - nblk + t: about 5 % of them at this shape), so "
+                                            "`achieved` counts bytes for those cells that are no longer moved",
             "launches": acc["launches"], "avg_launch_ms": dom_ms / max(acc["launches"], 1),
             "algorithmic_bytes_per_launch": acc["alg"] / max(acc["launches"], 1),
             "pair": {"kernel": kname + " + fix-up pass", "avg_launch_ms": acc["pair_ms"] / max(acc["tl"], 1),
