@@ -2086,16 +2086,19 @@ __device__ __forceinline__ int big_merge_rec(const Geometry& g, const uint32_t* 
   unsigned long long acc_hi = 0, rv0 = 0, rh0 = 0;
 
   if (valid) {
-    float h[NL]; uint32_t hf[NL];
+    float h[NL], h2[NL]; uint32_t hf[NL], hf2[NL];       // head and second entry of every list, transition score added
 #pragma unroll
     for (int i = 0; i < NL; ++i) {                                       // list heads (:750-761)
-      h[i] = NEG; hf[i] = 0;
+      h[i] = NEG; h2[i] = NEG; hf[i] = 0; hf2[i] = 0;
       if ((t.ok >> i) & 1u) {
-        const lva_u32x2 v = *LVA_GLOBAL(lva_u32x2, prev + lrec(i));
-        const bool ok = u2f(v.x) != NEG;
-        h[i] = ok ? u2f(v.x) + ladd(i) : NEG;
-        if (ok && !(h[i] > NEG)) why = 2;                  // non-finite sum: the exact path decides
+        const lva_u32x2 v = *LVA_GLOBAL(lva_u32x2, prev + lrec(i)), v2 = *LVA_GLOBAL(lva_u32x2, prev + lrec(i) + 8u);
+        const float add = ladd(i);
+        const bool ok = u2f(v.x) != NEG, ok2 = u2f(v2.x) != NEG;
+        h[i] = ok ? u2f(v.x) + add : NEG;
+        h2[i] = ok2 ? u2f(v2.x) + add : NEG;
+        if ((ok && !(h[i] > NEG)) || (ok2 && !(h2[i] > NEG))) why = 2;   // non-finite sum: the exact path decides
         hf[i] = i ? v.y ^ t.fpc : v.y;
+        hf2[i] = i ? v2.y ^ t.fpc : v2.y;
       }
     }
     uint32_t ah[LL];                 // accepted fingerprints, NEWEST FIRST (shift register: static indices only)
@@ -2123,7 +2126,7 @@ __device__ __forceinline__ int big_merge_rec(const Geometry& g, const uint32_t* 
       const bool accept = pred && !isdup, reject = pred && isdup;
       const uint32_t from9 = (sel << 6) | jj;
       const unsigned long long hi9 = (unsigned long long)(sel >> 2);
-      if (accept) s_acc[lc * NT] = (uint8_t)from9;
+      s_acc[lc * NT] = (uint8_t)from9;       // (whether accepted or not: the next accepted entry overwrites a rejected one's byte)
       acc_hi |= accept ? hi9 << lc : 0ull;
       const uint32_t ra = lc - 1u - (uint32_t)q;                 // the entry it matched (only meaningful when reject)
       const unsigned long long rbit = 1ull << (ra & 63u);
@@ -2142,8 +2145,16 @@ __device__ __forceinline__ int big_merge_rec(const Geometry& g, const uint32_t* 
       ah[0] = selv(accept, fp, ah[0]);
       lc += accept ? 1u : 0u;
     };
+    // A round's request -- the entry two behind the one it pops -- is consumed by the NEXT round, after that round's scan: a
+    // round never waits for the load it issued.  The loop body is two rounds with two sets of registers (a loop-carried copy
+    // of the loaded value would be its first use: the wait would sit at the end of the round that issued the load).
+    struct Pending { lva_u32x2 v; float add; uint32_t fx; bool has; bool eq[NL]; };
+    Pending pa, pb;
+    pb.v = lva_u32x2{kNegInfBits, 0u}; pb.add = 0.0f; pb.fx = 0; pb.has = false;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) pb.eq[i] = false;
     bool go = why == 0;
-    while (go) {                                                         // :764
+    auto round = [&](const Pending& pin, Pending& pout) __attribute__((always_inline)) {
       float M = h[0];
 #pragma unroll
       for (int i = 1; i < NL; ++i) M = fmaxf(M, h[i]);
@@ -2159,24 +2170,44 @@ __device__ __forceinline__ int big_merge_rec(const Geometry& g, const uint32_t* 
       const bool alive = M > NEG;            // false: every list exhausted (heap empty)
       const bool proceed = alive && !two;
       const uint32_t j = (uint32_t)(ptr >> (7 * sel)) & 127u;
-      // next entry of the popped list -- the neighbouring record: requested now, used after the scan (:788-796)
-      const bool has_next = j + 1 < L;
-      const lva_u32x2 nv = *LVA_GLOBAL(lva_u32x2, prev + lrec(sel) + (has_next ? j + 1 : j) * 8u);
+      // the entry two behind the popped one: requested now, waited for at the end of the NEXT round (:788-796)
+      const bool has2 = j + 2 < L;
+      // (The load and its wait are written out: the compiler's own wait for a value that crosses the loop's back edge sits at
+      //  the loop header -- one scan early.  One load per round, no other vector memory operation inside the loop: when a round
+      //  consumes the previous round's request, its own request is the only younger one -- vmcnt(1).)
+      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pout.v) : "v"(prev + lrec(sel) + (has2 ? j + 2 : j) * 8u) : "memory");
       uint32_t ch = hf[NL - 1];
 #pragma unroll
       for (int i = NL - 2; i >= 0; --i) ch = selv(eq[i], hf[i], ch);
       pop(proceed, sel, j, ch);
-      const float addsel = ladd(sel);
-      const bool nxt_ok = has_next && u2f(nv.x) != NEG;
-      const float ns = nxt_ok ? u2f(nv.x) + addsel : NEG;
-      const bool bad = nxt_ok && !(ns > NEG);   // overflowed to -inf: the reference would still queue it
-      const uint32_t nf = sel ? nv.y ^ t.fpc : nv.y;
+      // (1) the previous round's request has had two scans to arrive: it is the second entry of the list popped there
+      lva_u32x2 pinv = pin.v;
+      asm volatile("s_waitcnt vmcnt(1)" : "+v"(pinv) : : "memory");
+      const bool pok = pin.has && u2f(pinv.x) != NEG;
+      const float ps = pok ? u2f(pinv.x) + pin.add : NEG;
+      const bool bad = pok && !(ps > NEG);      // overflowed to -inf: the reference would still queue it
+      const uint32_t pf = pinv.y ^ pin.fx;
 #pragma unroll
-      for (int i = 0; i < NL; ++i) { h[i] = selv(eq[i], ns, h[i]); hf[i] = selv(eq[i], nf, hf[i]); }
+      for (int i = 0; i < NL; ++i) { h2[i] = selv(pin.eq[i], ps, h2[i]); hf2[i] = selv(pin.eq[i], pf, hf2[i]); }
+      // (2) the popped list's second entry becomes its head (its new second entry is this round's request)
+      float gs = h2[NL - 1]; uint32_t gfs = hf2[NL - 1];
+#pragma unroll
+      for (int i = NL - 2; i >= 0; --i) { gs = selv(eq[i], h2[i], gs); gfs = selv(eq[i], hf2[i], gfs); }
+#pragma unroll
+      for (int i = 0; i < NL; ++i) { h[i] = selv(eq[i], gs, h[i]); hf[i] = selv(eq[i], gfs, hf[i]); }
+#pragma unroll
+      for (int i = 0; i < NL; ++i) pout.eq[i] = eq[i];
+      pout.has = has2; pout.add = ladd(sel); pout.fx = sel ? t.fpc : 0u;
       ptr += 1ull << (7 * sel);
       why = (alive && two) ? 1 : ((proceed && bad) ? 2 : (rej_full ? 3 : 0));
       go = proceed && why == 0 && lc < L;
+    };
+    while (go) {                                                         // :764
+      round(pb, pa);
+      if (!go) break;
+      round(pa, pb);
     }
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");    // the last round's request: nobody reads it, but its registers are about to be reused
   }
 
   // ---- outputs: the whole wavefront, four entries of every target at a time (:771-774, :780-783, :799) ----
@@ -2195,39 +2226,48 @@ __device__ __forceinline__ int big_merge_rec(const Geometry& g, const uint32_t* 
   const uint32_t half = lane >> 5;
   uint32_t* trow = s_tr + ((wrow >> 1) + (lane & 31u)) * kTrRow;
   for (uint32_t l0 = 0; l0 < L; l0 += 4) {
-    lva_u32x4 ra4[4], rb4[4], oa[4], ob[4]; uint32_t q0[4][6]; uint32_t iu[4], ir[4];
+    // Every request of the round goes out before anything is waited for, and the four entries' records are requested and
+    // consumed by ALL lanes (a lane without an entry reads the first record of the buffer and ignores it): a load that is issued
+    // on some paths only has an unknown place in the queue, the compiler then waits for EVERYTHING in front of the next write to
+    // its register -- the four entries of a round used to be four round trips one after the other.
+    lva_u32x4 ra4[4], rb4[4], qa[4], oa[4], ob[4]; lva_u32x2 qb[4]; uint32_t iu[4], ir[4]; bool on[4], chk[4];
 #pragma unroll
     for (uint32_t u = 0; u < 4; ++u) {
       const uint32_t l = l0 + u;
-      iu[u] = 0; ir[u] = 0;
-      if (act && l < lc) {
-        const uint32_t f = locate((uint32_t)s_acc[l * NT] | ((uint32_t)(acc_hi >> l) & 1u) << 8, &iu[u]);
-        ra4[u] = *LVA_GLOBAL(lva_u32x4, prev + f);          // score, fingerprint, words 4-5
-        rb4[u] = *LVA_GLOBAL(lva_u32x4, prev + f + 4);      // words 0-3
-        if ((rv0 >> l) & 1ull) {          // the match filed under this entry: its loads travel with the others
-          const uint32_t fr = locate((uint32_t)s_rej0[l * NT] | ((uint32_t)(rh0 >> l) & 1u) << 8, &ir[u]);
-          const lva_u32x4 a = *LVA_GLOBAL(lva_u32x4, prev + fr + 4);
-          const lva_u32x2 b = *LVA_GLOBAL(lva_u32x2, prev + fr + 2);
-          q0[u][0] = a.x; q0[u][1] = a.y; q0[u][2] = a.z; q0[u][3] = a.w; q0[u][4] = b.x; q0[u][5] = b.y;
-        }
+      on[u] = act && l < lc;
+      uint32_t i0 = 0;
+      const uint32_t f = locate((uint32_t)s_acc[l * NT] | ((uint32_t)(acc_hi >> l) & 1u) << 8, &i0);
+      iu[u] = on[u] ? i0 : 0u;
+      const uint32_t* rp = prev + (on[u] ? f : 0u);
+      ra4[u] = *LVA_GLOBAL(lva_u32x4, rp);                // score, fingerprint, words 4-5
+      rb4[u] = *LVA_GLOBAL(lva_u32x4, rp + 4);            // words 0-3
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {                    // the match filed under an entry (one in ten): its loads travel with the others
+      const uint32_t l = l0 + u;
+      chk[u] = on[u] && ((rv0 >> l) & 1ull);
+      ir[u] = 0; qa[u] = lva_u32x4{0u, 0u, 0u, 0u}; qb[u] = lva_u32x2{0u, 0u};
+      if (chk[u]) {
+        const uint32_t fr = locate((uint32_t)s_rej0[l * NT] | ((uint32_t)(rh0 >> l) & 1u) << 8, &ir[u]);
+        qa[u] = *LVA_GLOBAL(lva_u32x4, prev + fr + 4);
+        qb[u] = *LVA_GLOBAL(lva_u32x2, prev + fr + 2);
       }
     }
 #pragma unroll
     for (uint32_t u = 0; u < 4; ++u) {
-      const uint32_t l = l0 + u;
-      oa[u] = lva_u32x4{kNegInfBits, 0u, 0u, 0u}; ob[u] = lva_u32x4{0u, 0u, 0u, 0u};      // (:799) the unused tail of the list
-      if (act && l < lc) {
-        uint32_t m[6] = {rb4[u].x, rb4[u].y, rb4[u].z, rb4[u].w, ra4[u].z, ra4[u].w};
-        const float sc = u2f(ra4[u].x) + ladd(iu[u]);
-        push_var<6>(m, iu[u] == 0 ? 0u : t.sh, iu[u] == 0 ? 0u : t.nb);
-        oa[u].x = f2u(sc); oa[u].y = iu[u] ? ra4[u].y ^ t.fpc : ra4[u].y; oa[u].z = m[4]; oa[u].w = m[5];
-        ob[u].x = m[0]; ob[u].y = m[1]; ob[u].z = m[2]; ob[u].w = m[3];
-        if ((rv0 >> l) & 1ull) {
-          push_bits<6>(q0[u], ir[u] == 0 ? 0u : t.sh, t.nb);
+      uint32_t m[6] = {rb4[u].x, rb4[u].y, rb4[u].z, rb4[u].w, ra4[u].z, ra4[u].w};
+      const float sc = u2f(ra4[u].x) + ladd(iu[u]);
+      push_var<6>(m, iu[u] == 0 ? 0u : t.sh, iu[u] == 0 ? 0u : t.nb);
+      // (:799) the unused tail of the list: -inf, empty message
+      oa[u].x = on[u] ? f2u(sc) : kNegInfBits; oa[u].y = on[u] ? (iu[u] ? ra4[u].y ^ t.fpc : ra4[u].y) : 0u;
+      oa[u].z = on[u] ? m[4] : 0u; oa[u].w = on[u] ? m[5] : 0u;
+      ob[u].x = on[u] ? m[0] : 0u; ob[u].y = on[u] ? m[1] : 0u; ob[u].z = on[u] ? m[2] : 0u; ob[u].w = on[u] ? m[3] : 0u;
+      uint32_t q[6] = {qa[u].x, qa[u].y, qa[u].z, qa[u].w, qb[u].x, qb[u].y};
+      push_var<6>(q, ir[u] == 0 ? 0u : t.sh, ir[u] == 0 ? 0u : t.nb);
+      uint32_t diff = 0;
 #pragma unroll
-          for (int w = 0; w < 6; ++w) good &= (q0[u][w] == m[w]);
-        }
-      }
+      for (int w = 0; w < 6; ++w) diff |= q[w] ^ m[w];
+      good &= !(chk[u] && diff != 0);
     }
     // whole lines out, half a wavefront's targets per round: instruction s stores the 128 bytes (4 records) of targets
     // 32h + 8s .. 32h + 8s + 7, 16 bytes per thread
@@ -2242,15 +2282,19 @@ __device__ __forceinline__ int big_merge_rec(const Geometry& g, const uint32_t* 
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      uint32_t tb[4]; lva_u32x4 tv[4];                    // (all eight LDS reads requested before the first store waits for one)
 #pragma unroll
       for (uint32_t s8 = 0; s8 < 4; ++s8) {
         const uint32_t Tl = 8 * s8 + (lane >> 3), piece = lane & 7u;       // target (local to the half), 16-byte piece of its line
-        const uint32_t base = s_base[wrow + 32 * h2 + Tl];
-        if (base != 0xFFFFFFFFu) {
-          const lva_u32x4 v = *reinterpret_cast<const lva_u32x4*>(s_tr + ((wrow >> 1) + Tl) * kTrRow + 4 * piece);
-          uint32_t* dst = cur + base + l0 * 8u + 4 * piece;
-          __builtin_nontemporal_store(v.x, dst); __builtin_nontemporal_store(v.y, dst + 1);
-          __builtin_nontemporal_store(v.z, dst + 2); __builtin_nontemporal_store(v.w, dst + 3);
+        tb[s8] = s_base[wrow + 32 * h2 + Tl];
+        tv[s8] = *reinterpret_cast<const lva_u32x4*>(s_tr + ((wrow >> 1) + Tl) * kTrRow + 4 * piece);
+      }
+#pragma unroll
+      for (uint32_t s8 = 0; s8 < 4; ++s8) {
+        if (tb[s8] != 0xFFFFFFFFu) {
+          uint32_t* dst = cur + tb[s8] + l0 * 8u + 4 * (lane & 7u);
+          __builtin_nontemporal_store(tv[s8].x, dst); __builtin_nontemporal_store(tv[s8].y, dst + 1);
+          __builtin_nontemporal_store(tv[s8].z, dst + 2); __builtin_nontemporal_store(tv[s8].w, dst + 3);
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
