@@ -2086,19 +2086,16 @@ __device__ __forceinline__ int big_merge_rec(const Geometry& g, const uint32_t* 
   unsigned long long acc_hi = 0, rv0 = 0, rh0 = 0;
 
   if (valid) {
-    float h[NL], h2[NL]; uint32_t hf[NL], hf2[NL];       // head and second entry of every list, transition score added
+    float h[NL]; uint32_t hf[NL];
 #pragma unroll
     for (int i = 0; i < NL; ++i) {                                       // list heads (:750-761)
-      h[i] = NEG; h2[i] = NEG; hf[i] = 0; hf2[i] = 0;
+      h[i] = NEG; hf[i] = 0;
       if ((t.ok >> i) & 1u) {
-        const lva_u32x2 v = *LVA_GLOBAL(lva_u32x2, prev + lrec(i)), v2 = *LVA_GLOBAL(lva_u32x2, prev + lrec(i) + 8u);
-        const float add = ladd(i);
-        const bool ok = u2f(v.x) != NEG, ok2 = u2f(v2.x) != NEG;
-        h[i] = ok ? u2f(v.x) + add : NEG;
-        h2[i] = ok2 ? u2f(v2.x) + add : NEG;
-        if ((ok && !(h[i] > NEG)) || (ok2 && !(h2[i] > NEG))) why = 2;   // non-finite sum: the exact path decides
+        const lva_u32x2 v = *LVA_GLOBAL(lva_u32x2, prev + lrec(i));
+        const bool ok = u2f(v.x) != NEG;
+        h[i] = ok ? u2f(v.x) + ladd(i) : NEG;
+        if (ok && !(h[i] > NEG)) why = 2;                  // non-finite sum: the exact path decides
         hf[i] = i ? v.y ^ t.fpc : v.y;
-        hf2[i] = i ? v2.y ^ t.fpc : v2.y;
       }
     }
     uint32_t ah[LL];                 // accepted fingerprints, NEWEST FIRST (shift register: static indices only)
@@ -2126,7 +2123,7 @@ __device__ __forceinline__ int big_merge_rec(const Geometry& g, const uint32_t* 
       const bool accept = pred && !isdup, reject = pred && isdup;
       const uint32_t from9 = (sel << 6) | jj;
       const unsigned long long hi9 = (unsigned long long)(sel >> 2);
-      s_acc[lc * NT] = (uint8_t)from9;       // (whether accepted or not: the next accepted entry overwrites a rejected one's byte)
+      if (accept) s_acc[lc * NT] = (uint8_t)from9;
       acc_hi |= accept ? hi9 << lc : 0ull;
       const uint32_t ra = lc - 1u - (uint32_t)q;                 // the entry it matched (only meaningful when reject)
       const unsigned long long rbit = 1ull << (ra & 63u);
@@ -2145,16 +2142,8 @@ __device__ __forceinline__ int big_merge_rec(const Geometry& g, const uint32_t* 
       ah[0] = selv(accept, fp, ah[0]);
       lc += accept ? 1u : 0u;
     };
-    // A round's request -- the entry two behind the one it pops -- is consumed by the NEXT round, after that round's scan: a
-    // round never waits for the load it issued.  The loop body is two rounds with two sets of registers (a loop-carried copy
-    // of the loaded value would be its first use: the wait would sit at the end of the round that issued the load).
-    struct Pending { lva_u32x2 v; float add; uint32_t fx; bool has; bool eq[NL]; };
-    Pending pa, pb;
-    pb.v = lva_u32x2{kNegInfBits, 0u}; pb.add = 0.0f; pb.fx = 0; pb.has = false;
-#pragma unroll
-    for (int i = 0; i < NL; ++i) pb.eq[i] = false;
     bool go = why == 0;
-    auto round = [&](const Pending& pin, Pending& pout) __attribute__((always_inline)) {
+    while (go) {                                                         // :764
       float M = h[0];
 #pragma unroll
       for (int i = 1; i < NL; ++i) M = fmaxf(M, h[i]);
@@ -2170,44 +2159,24 @@ __device__ __forceinline__ int big_merge_rec(const Geometry& g, const uint32_t* 
       const bool alive = M > NEG;            // false: every list exhausted (heap empty)
       const bool proceed = alive && !two;
       const uint32_t j = (uint32_t)(ptr >> (7 * sel)) & 127u;
-      // the entry two behind the popped one: requested now, waited for at the end of the NEXT round (:788-796)
-      const bool has2 = j + 2 < L;
-      // (The load and its wait are written out: the compiler's own wait for a value that crosses the loop's back edge sits at
-      //  the loop header -- one scan early.  One load per round, no other vector memory operation inside the loop: when a round
-      //  consumes the previous round's request, its own request is the only younger one -- vmcnt(1).)
-      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pout.v) : "v"(prev + lrec(sel) + (has2 ? j + 2 : j) * 8u) : "memory");
+      // next entry of the popped list -- the neighbouring record: requested now, used after the scan (:788-796)
+      const bool has_next = j + 1 < L;
+      const lva_u32x2 nv = *LVA_GLOBAL(lva_u32x2, prev + lrec(sel) + (has_next ? j + 1 : j) * 8u);
       uint32_t ch = hf[NL - 1];
 #pragma unroll
       for (int i = NL - 2; i >= 0; --i) ch = selv(eq[i], hf[i], ch);
       pop(proceed, sel, j, ch);
-      // (1) the previous round's request has had two scans to arrive: it is the second entry of the list popped there
-      lva_u32x2 pinv = pin.v;
-      asm volatile("s_waitcnt vmcnt(1)" : "+v"(pinv) : : "memory");
-      const bool pok = pin.has && u2f(pinv.x) != NEG;
-      const float ps = pok ? u2f(pinv.x) + pin.add : NEG;
-      const bool bad = pok && !(ps > NEG);      // overflowed to -inf: the reference would still queue it
-      const uint32_t pf = pinv.y ^ pin.fx;
+      const float addsel = ladd(sel);
+      const bool nxt_ok = has_next && u2f(nv.x) != NEG;
+      const float ns = nxt_ok ? u2f(nv.x) + addsel : NEG;
+      const bool bad = nxt_ok && !(ns > NEG);   // overflowed to -inf: the reference would still queue it
+      const uint32_t nf = sel ? nv.y ^ t.fpc : nv.y;
 #pragma unroll
-      for (int i = 0; i < NL; ++i) { h2[i] = selv(pin.eq[i], ps, h2[i]); hf2[i] = selv(pin.eq[i], pf, hf2[i]); }
-      // (2) the popped list's second entry becomes its head (its new second entry is this round's request)
-      float gs = h2[NL - 1]; uint32_t gfs = hf2[NL - 1];
-#pragma unroll
-      for (int i = NL - 2; i >= 0; --i) { gs = selv(eq[i], h2[i], gs); gfs = selv(eq[i], hf2[i], gfs); }
-#pragma unroll
-      for (int i = 0; i < NL; ++i) { h[i] = selv(eq[i], gs, h[i]); hf[i] = selv(eq[i], gfs, hf[i]); }
-#pragma unroll
-      for (int i = 0; i < NL; ++i) pout.eq[i] = eq[i];
-      pout.has = has2; pout.add = ladd(sel); pout.fx = sel ? t.fpc : 0u;
+      for (int i = 0; i < NL; ++i) { h[i] = selv(eq[i], ns, h[i]); hf[i] = selv(eq[i], nf, hf[i]); }
       ptr += 1ull << (7 * sel);
       why = (alive && two) ? 1 : ((proceed && bad) ? 2 : (rej_full ? 3 : 0));
       go = proceed && why == 0 && lc < L;
-    };
-    while (go) {                                                         // :764
-      round(pb, pa);
-      if (!go) break;
-      round(pa, pb);
     }
-    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");    // the last round's request: nobody reads it, but its registers are about to be reused
   }
 
   // ---- outputs: the whole wavefront, four entries of every target at a time (:771-774, :780-783, :799) ----

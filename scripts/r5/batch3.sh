@@ -1,0 +1,2 @@
+#!/bin/bash
+bash scripts/run_variants.sh gpurun_out/r5v3 "--list-size 64 --slots 8 --steps 1 --warmup 0 --pool 8 --cross-check-reads 1" default out2 merge2
