@@ -101,6 +101,40 @@ def as_lines(res):
     return ["".join("1" if b else "0" for b in row) for row in res[0]]
 
 
+class StubDecoder:
+    """LVA_BENCH_STUB=1 together with LVA_TESTING=1 (tests/test_sharding_gloo.py): a stand-in for the GPU decoder so that the
+    8-rank argument / shard / gather / JSON path of this script runs in a container without GPUs.  Never measures anything."""
+
+    def __init__(self, list_size, msg_len, slots):
+        self.L, self.ml, self.slots, self.p = list_size, msg_len, slots or 64, None
+
+    def profile(self):
+        return self.p or dict(slots=self.slots, kernel=1)
+
+    def set_launch_events(self, on):
+        pass
+
+    def decode_packed(self, flat, off, rc):
+        import numpy as np
+        out = []
+        for i in range(len(off) - 1):
+            n = int(off[i + 1] - off[i])
+            if n < 5:
+                out.append(-6)                            # LVA_ERR_POST_TOO_SHORT
+                continue
+            cnt = 1 + n % self.L
+            msgs = ((np.arange(cnt * self.ml).reshape(cnt, self.ml) + n + int(rc[i])) % 2).astype(np.uint8)
+            out.append((msgs, -np.arange(cnt, dtype=np.float32) - n))
+        nb = int(off[-1] - off[0])
+        self.p = dict(slots=self.slots, kernel=1, step_kernel_ms=1.0, dominant_kernel_ms=1.0, step_pair_ms=1.0, algorithmic_bytes=1e6 * nb,
+                      working_bytes=9e5 * nb, step_launches=nb, timed_launches=nb, read_steps=nb, fixup_states=0, h2d_ms=0.0,
+                      h2d_bytes=160 * nb, total_ms=1.0, fixup_reason=[0, 0, 0, 0])
+        return out
+
+    def close(self):
+        pass
+
+
 def main():
     a = parse()
     in_group = "WORLD_SIZE" in os.environ
@@ -120,10 +154,13 @@ def main():
         raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (a.gpus, world))
 
     import nanopore_dna_storage_amd as pkg
-    from nanopore_dna_storage_amd import synth
+    from nanopore_dna_storage_amd import synth, _lib
 
-    dec = pkg.Decoder(a.mem_conv, a.rate, a.msg_len, list_size=a.list_size, max_deviation=a.max_deviation,
-                      device=devno, max_slots=a.slots, kernel=a.kernel)
+    L = pkg.load_library()
+    build_id = _lib.build_id()
+    stub = os.environ.get("LVA_BENCH_STUB") == "1" and os.environ.get("LVA_TESTING") == "1"
+    dec = StubDecoder(a.list_size, a.msg_len, a.slots) if stub else pkg.Decoder(
+        a.mem_conv, a.rate, a.msg_len, list_size=a.list_size, max_deviation=a.max_deviation, device=devno, max_slots=a.slots, kernel=a.kernel)
     slots = dec.profile()["slots"]
     if dist is not None and backend == "nccl":
         sharding.assert_one_gpu_per_rank(dist)
@@ -143,6 +180,8 @@ def main():
         shards = [np.arange(r * per_step, (r + 1) * per_step, dtype=np.int64) for r in range(world)]
 
     def make(gi):      # global read index -> read; every 5th read noisy (margin 3), odd reads reverse-complemented
+        if stub:       # (a few blocks of zeros, some of them too short to decode: error codes travel through the gather too)
+            return dict(post=np.zeros((3 + (gi * 7919) % 57, 40), np.float32), rc=bool(gi & 1))
         return synth.make_read(a.mem_conv, a.rate, a.msg_len, seed=1000 + gi, rc=bool(gi & 1),
                                margin=3.0 if gi % 5 == 0 else 6.0)
 
@@ -182,7 +221,7 @@ def main():
         outs[step_no % nbatch] = run(batches[step_no % nbatch]); step_no += 1
     dec.set_launch_events(not a.no_launch_events)
     barrier()
-    acc = dict(span_ms=0.0, dom_ms=0.0, pair_ms=0.0, alg=0.0, launches=0, tl=0, read_steps=0, fix=0, h2d_ms=0.0, h2d_b=0,
+    acc = dict(span_ms=0.0, dom_ms=0.0, pair_ms=0.0, alg=0.0, moved=0.0, launches=0, tl=0, read_steps=0, fix=0, h2d_ms=0.0, h2d_b=0,
                total_ms=0.0)
     fixr = [0, 0, 0, 0]
     t0 = time.perf_counter()
@@ -191,7 +230,7 @@ def main():
         outs[b] = run(batches[b]); step_no += 1     # returns after the stream is drained and the lists are on the host
         p = dec.profile()
         acc["span_ms"] += p["step_kernel_ms"]; acc["dom_ms"] += p["dominant_kernel_ms"]; acc["pair_ms"] += p["step_pair_ms"]
-        acc["alg"] += p["algorithmic_bytes"]; acc["launches"] += p["step_launches"]; acc["tl"] += p["timed_launches"]
+        acc["alg"] += p["algorithmic_bytes"]; acc["moved"] += p["working_bytes"]; acc["launches"] += p["step_launches"]; acc["tl"] += p["timed_launches"]
         acc["read_steps"] += p["read_steps"]; acc["fix"] += p["fixup_states"]
         acc["h2d_ms"] += p["h2d_ms"]; acc["h2d_b"] += p["h2d_bytes"]; acc["total_ms"] += p["total_ms"]
         fixr = [x + y for x, y in zip(fixr, p["fixup_reason"])]
@@ -248,6 +287,9 @@ def main():
                        "gathered_lists": n_global, "mean_active_slots": acc["read_steps"] / max(acc["launches"], 1),
                        "dist_backend": dist.get_backend() if dist is not None else None, "world": world,
                        "per_rank": per_rank},
+            # the library that was measured: lva_version() carries a hash of its source files (csrc/Makefile); counter files
+            # under profiles/ name the build they were taken on, and `traffic` below is only filled from a file of THIS build
+            "library": {"version": L.lva_version().decode(), "build_id": build_id},
         }
         use_events = acc["tl"] > 0
         dom_ms = acc["dom_ms"] if use_events else acc["span_ms"]
@@ -261,21 +303,30 @@ def main():
         # passes, scripts/pmc_mem.sh), per read-step, scaled to this run's mean number of active slots per launch
         traffic, tsrc, limiter = None, None, None
         try:
-            for name in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+            for name in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
                 pth = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(pth):
                     tj = json.load(open(pth))
                     if ((a.mem_conv, a.rate, a.list_size, a.msg_len, a.max_deviation) == (11, 5, 8, 180, 20) and acc["launches"]
                             and tj.get("kernel_mode", 2) == prof["kernel"]):
-                        per_rs = (tj["fetch_correction"] * tj["fetch_size_kb_per_launch"] + tj["write_size_kb_per_launch"]) * 1024.0 / tj["slots"]
-                        traffic = per_rs * (acc["read_steps"] / acc["launches"])
-                        tsrc = "profiles/" + name + " (PMC run of an earlier invocation, scaled per read-step)"
-                        limiter = tj.get("limiter")
+                        if tj.get("build_id") == build_id:
+                            per_rs = (tj["fetch_correction"] * tj["fetch_size_kb_per_launch"] + tj["write_size_kb_per_launch"]) * 1024.0 / tj["slots"]
+                            traffic = per_rs * (acc["read_steps"] / acc["launches"])
+                            tsrc = "profiles/" + name + " (PMC passes over the same library build, scaled per read-step to this run's active slots)"
+                            limiter = tj.get("limiter")
+                        else:
+                            tsrc = ("profiles/%s was measured on library build %s, this run is build %s: no traffic figure for this run"
+                                    % (name, tj.get("build_id", "(unnamed, before round 5)"), build_id))
                     break
         except Exception:
             traffic = None
+        moved = (acc["moved"] / 1e9) / (dom_ms / 1e3) if dom_ms > 0 else 0.0
         res["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+            # the same with the bytes of the band the kernels actually work on (lva_band_table's working band): what is MOVED per
+            # second.  `frac` keeps SURVEY 8(d)'s definition (the reference's band) so that rounds stay comparable.
+            "achieved_moved": moved, "frac_moved": moved / 8000.0,
+            "working_band_bytes_per_launch": acc["moved"] / max(acc["launches"], 1),
             "traffic": traffic, "traffic_source": tsrc,
             # what the counters say holds the kernel back (the HBM roofline above stays the yardstick of the contract):
             # from the committed PMC profile of the same kernels, not measured in this run
@@ -286,7 +337,8 @@ def main():
             "algorithmic_bytes_definition": "SURVEY 8(d): sum over time steps of the structurally reachable in-band states of the "
                                             "REFERENCE's band; since round 4 the kernels skip the cells of that band whose lists cannot reach the "
                                             "output (positions > t + 1 and < nstate_pos - nblk + t: about 5 % of them at this shape), so "
-                                            "`achieved` counts bytes for those cells that are no longer moved",
+                                            "`achieved` counts bytes for those cells that are no longer moved -- `achieved_moved` / `frac_moved` "
+                                            "count the working band's cells only",
             "launches": acc["launches"], "avg_launch_ms": dom_ms / max(acc["launches"], 1),
             "algorithmic_bytes_per_launch": acc["alg"] / max(acc["launches"], 1),
             "pair": {"kernel": kname + " + fix-up pass", "avg_launch_ms": acc["pair_ms"] / max(acc["tl"], 1),

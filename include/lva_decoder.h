@@ -79,7 +79,8 @@ typedef struct lva_profile {
   uint64_t step_launches;     /* trellis-step kernel launches */
   uint64_t read_steps;        /* sum over reads of nblk (one launch advances every active read one step) */
   double algorithmic_bytes;   /* sum over reads of sum_t [2 R(t) L (4+4W) + 160] */
-  uint64_t fixup_states;      /* states redone by the exact kernel (kernel mode 2) */
+  uint64_t fixup_states;      /* states redone by the exact kernel (kernel mode 2); a launch whose work list overflowed
+                                 counts in overflow_steps instead (every state of the step was redone) */
   uint64_t fixup_reason[4];   /* of which: score tie on top, non-finite arithmetic, too many fingerprint
                                  matches, fingerprint collision */
   int32_t slots;              /* reads in flight */
@@ -92,9 +93,18 @@ typedef struct lva_profile {
   uint64_t h2d_bytes;
   uint64_t overflow_steps;    /* launches whose work list of undecided targets overflowed: the exact path redid the whole
                                  step (tie-dense posteriors; correct, but a large slow-down the caller can now see) */
+  double working_bytes;       /* algorithmic_bytes' sum over the band the kernels actually work on (lva_band_table's
+                                 working_lo_hi): the bytes that are moved, about 5 % fewer at the benchmark shape */
 } lva_profile;
 
+/* "lva_hip <abi>.<n> (gfx950) build <id>": <id> is a hash of the library's source files taken when it was built
+ * (csrc/Makefile), so that a profile or a counter file can name the library it was measured on (bench.py writes it into
+ * every JSON line; profiles/ *_traffic.json carry it). */
 const char *lva_version(void);
+/* LVA_ABI_VERSION of the library that was loaded.  It changes whenever a struct of this header changes size or layout
+ * (5: lva_profile gained overflow_steps and working_bytes): a caller built against another value must not pass structs. */
+#define LVA_ABI_VERSION 5
+int lva_abi_version(void);
 const char *lva_strerror(int code);
 const char *lva_last_hip_error(void);
 

@@ -6,6 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_NAME = "liblva_hip.so"
 
 MAX_DEVIATION_DEFAULT = 0xFFFFFFFF
+ABI_VERSION = 5                # LVA_ABI_VERSION of include/lva_decoder.h
 
 ERRORS = {
     -1: "LVA_ERR_MEM_CONV", -2: "LVA_ERR_RATE", -3: "LVA_ERR_MSG_LEN", -4: "LVA_ERR_SYNC",
@@ -16,7 +17,7 @@ ERRORS = {
 
 # every symbol include/lva_decoder.h declares
 EXPORTS = [
-    "lva_version", "lva_strerror", "lva_last_hip_error", "lva_code_describe", "lva_code_tables", "lva_band_table",
+    "lva_version", "lva_abi_version", "lva_strerror", "lva_last_hip_error", "lva_code_describe", "lva_code_tables", "lva_band_table",
     "lva_encode", "lva_algorithmic_bytes", "lva_decoder_create", "lva_decoder_destroy",
     "lva_decode_batch", "lva_decode_batch_device", "lva_decoder_profile", "lva_decoder_set_launch_events", "lva_device_alloc",
     "lva_device_free", "lva_device_upload", "lva_device_synchronize",
@@ -63,7 +64,7 @@ class Profile(ctypes.Structure):
                 ("slots", ctypes.c_int32), ("kernel", ctypes.c_int32),
                 ("dominant_kernel_ms", ctypes.c_double), ("step_pair_ms", ctypes.c_double),
                 ("timed_launches", ctypes.c_uint64), ("h2d_ms", ctypes.c_double), ("h2d_bytes", ctypes.c_uint64),
-                ("overflow_steps", ctypes.c_uint64)]
+                ("overflow_steps", ctypes.c_uint64), ("working_bytes", ctypes.c_double)]
 
 
 class PayloadPos(ctypes.Structure):
@@ -72,6 +73,11 @@ class PayloadPos(ctypes.Structure):
 
 
 _lib = None
+
+
+def build_id():
+    """The source hash the loaded library was built from (lva_version(): '... build <id>')."""
+    return load_library().lva_version().decode().rsplit("build ", 1)[-1]
 
 
 def library_path():
@@ -92,6 +98,10 @@ def load_library():
     vp, i32, u32, u64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint64
     cp = ctypes.c_char_p
     L.lva_version.restype = cp
+    L.lva_abi_version.restype = ctypes.c_int
+    if L.lva_abi_version() != ABI_VERSION:
+        raise ImportError("%s has ABI version %d, this package was written for %d (struct layouts of include/lva_decoder.h): rebuild it"
+                          % (path, L.lva_abi_version(), ABI_VERSION))
     L.lva_strerror.restype = cp
     L.lva_strerror.argtypes = [ctypes.c_int]
     L.lva_last_hip_error.restype = cp

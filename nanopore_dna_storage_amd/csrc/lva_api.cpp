@@ -83,7 +83,12 @@ struct StreamDrain {
 
 extern "C" {
 
-const char* lva_version(void) { return "lva_hip 0.1 (gfx950)"; }
+#ifndef LVA_BUILD_ID
+#define LVA_BUILD_ID "unknown"
+#endif
+const char* lva_version(void) { return "lva_hip 5.0 (gfx950) build " LVA_BUILD_ID; }
+
+int lva_abi_version(void) { return LVA_ABI_VERSION; }
 
 const char* lva_last_hip_error(void) { return g_hip_error.c_str(); }
 
@@ -152,22 +157,9 @@ int lva_encode(int32_t mem_conv, int32_t rate, uint32_t msg_len, const uint8_t* 
   return LVA_OK;
 }
 
-// The band of time step t the kernels work on: the reference's (:677-679, Code::band) without the positions whose lists
-// cannot matter.
-//  * A path advances at most one position per time step, so after step t only positions <= t + 1 hold a finite score: the
-//    reference writes -inf lists above (:799), the kernels neither write nor read them -- the band ends at t + 2 for them, and
-//    "beyond the previous band end" already reads as -inf (the upper band edge).  3.8 % of a read's (step, position) pairs.
-//  * A state at position p after step t can still reach the final position only if p >= npos - nblk + t; states below feed
-//    nothing that the final selection (:806-824) reads -- a state's predecessors lie one position lower or one step earlier, so
-//    states that matter depend on states that matter only -- and are neither written nor read: the band starts there.  1.2 %.
-// (tests/test_host_logic.py checks both against a reachability computation on the reference's band.)
+// the band of time step t the kernels work on: Code::working_band (lva_code.cpp)
 static void working_band(const Code& c, uint32_t t, uint32_t nblk, uint32_t max_dev, uint32_t* lo_out, uint32_t* hi_out) {
-  uint32_t lo, hi;
-  c.band(t, nblk, max_dev, &lo, &hi);
-  hi = std::min<uint32_t>(hi, t + 2);
-  const int64_t alive = (int64_t)c.npos - (int64_t)nblk + (int64_t)t;
-  if (alive > (int64_t)lo) lo = (uint32_t)std::min<int64_t>(alive, hi);
-  *lo_out = lo; *hi_out = hi;
+  c.working_band(t, nblk, max_dev, lo_out, hi_out);
 }
 
 int lva_band_table(int32_t mem_conv, int32_t rate, uint32_t msg_len, int32_t rc, const char* sync_marker, uint32_t sync_period,
@@ -226,12 +218,28 @@ static int upload_codes(lva_decoder* d) {
       r.vmask = c.vmask[p]; r.vval = c.vval[p]; r.vmask1 = c.vmask[q]; r.vval1 = c.vval[q];
       for (int nb = 0; nb < 4; ++nb) r.fpc[nb] = c.fpc[p][nb];
       r.np2 = p >= 2 ? dc[o].npair[p - 2] : 1u;
-      auto one_bit = [&](int64_t q) -> uint32_t { return q >= 1 && dc[o].ptype[q] == 0 ? 1u : 0u; };   // compact lists there (Geometry::cmp)
+      auto one_bit = [&](int64_t at) -> uint32_t { return at >= 1 && dc[o].ptype[at] == 0 ? 1u : 0u; };   // compact lists there (Geometry::cmp)
       r.cmp3 = one_bit(p) | one_bit((int64_t)p - 1) << 1 | one_bit((int64_t)p - 2) << 2;
       r.pad1 = 0;
       r.pred = dc[o].predtab[dc[o].ptype[p] & 3]; r.pred1 = dc[o].predtab[dc[o].ptype[q] & 3];
     }
   }
+  // Compact lists (Geometry::cmp) store crf state k's list as list k >> 1 at a one-bit position: that needs the reachable bases
+  // of every valid conv state there to be a complementary pair ({A,T} or {C,G}).  True of the four built-in generator pairs
+  // (tests/test_code_tables.py); checked here so that a code added later cannot alias two lists silently.
+  if (d->g.cmp)
+    for (int o = 0; o < 2; ++o) {
+      const Code& c = d->code[o];
+      for (uint32_t p = 1; p < c.npos; ++p) {
+        if (c.ptype[p] != 0 || c.predtab[0].empty()) continue;
+        for (uint32_t cv = 0; cv < N; ++cv) {
+          if ((cv & c.vmask[p]) != c.vval[p]) continue;
+          const uint32_t pk = c.predtab[0][cv];
+          const uint32_t has = ((pk >> 3) & 1u) | (((pk >> 7) & 1u) << 1) | (((pk >> 11) & 1u) << 2) | (((pk >> 15) & 1u) << 3);
+          if (has != 0x9u && has != 0x6u && has != 0u) return LVA_ERR_UNSUPPORTED;
+        }
+      }
+    }
   HIP_TRY(hipMalloc(&d->d_codes, sizeof dc));
   HIP_TRY(hipMemcpy(d->d_codes, dc, sizeof dc, hipMemcpyHostToDevice));
   return LVA_OK;
@@ -336,9 +344,12 @@ int lva_decoder_create(const lva_config* cfg, lva_decoder** out) {
   d->kernel = cfg->kernel == 1 ? 1 : cfg->kernel == 3 ? 3 : lazy ? 4 : (fast_ok ? 2 : (wave_kernel_available(d->g) ? 3 : 1));
   if (d->kernel == 4 && (!fast_ok || c.nconv < 64)) return fail(LVA_ERR_UNSUPPORTED);
   d->prof.kernel = d->kernel;
-  if (const char* cap = std::getenv("LVA_WORK_CAP")) {       // tests: force the work-list overflow path
+  // tests: force the work-list overflow path.  Honoured only together with LVA_TESTING=1 -- a stray LVA_WORK_CAP in a user's
+  // environment would cost an order of magnitude silently (visible through lva_profile.overflow_steps only)
+  if (const char* cap = std::getenv("LVA_WORK_CAP")) {
+    const char* testing = std::getenv("LVA_TESTING");
     const long v = std::atol(cap);
-    if (v >= 1 && v <= (1l << 24)) d->work_cap = (uint32_t)v;
+    if (testing && testing[0] == '1' && v >= 1 && v <= (1l << 24)) d->work_cap = (uint32_t)v;
   }
   if (hipMalloc(&d->d_work, sizeof(WorkHdr) + (size_t)d->work_cap * sizeof(uint32_t)) != hipSuccess) return fail(LVA_ERR_NOMEM);
   *out = d;
@@ -489,7 +500,7 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
   std::vector<Slot> slot((size_t)std::min<size_t>((size_t)d->slots, std::max<size_t>(order.size(), 1)));
   size_t next = 0;
   gathered.assign((size_t)n, 0);
-  d->prof.step_launches = 0; d->prof.read_steps = 0; d->prof.algorithmic_bytes = 0; d->prof.fixup_states = 0; d->prof.overflow_steps = 0;
+  d->prof.step_launches = 0; d->prof.read_steps = 0; d->prof.algorithmic_bytes = 0; d->prof.working_bytes = 0; d->prof.fixup_states = 0; d->prof.overflow_steps = 0;
   d->prof.dominant_kernel_ms = 0; d->prof.step_pair_ms = 0; d->prof.timed_launches = 0;
   const uint32_t band_max = std::min<uint32_t>(npos, 2 * d->max_dev);
   bool first_step = true;
@@ -522,6 +533,7 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
       const int e = launch_init_slot(g, d->d_codes, d->d_trellis, (uint32_t)s, sd, d->d_slots, d->stream);
       if (e) { g_hip_error = hipGetErrorString((hipError_t)e); return LVA_ERR_HIP; }
       d->prof.algorithmic_bytes += d->code[sd.orient].algorithmic_bytes(sd.nblk, L, d->max_dev);
+      d->prof.working_bytes += d->code[sd.orient].working_bytes(sd.nblk, L, d->max_dev);
       ++active;
     }
     if (active == 0) break;

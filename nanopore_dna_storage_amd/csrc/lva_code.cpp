@@ -222,18 +222,39 @@ void Code::band(uint32_t t, uint32_t nblk, uint32_t max_dev, uint32_t* lo, uint3
   *lo = start; *hi = end;
 }
 
-double Code::algorithmic_bytes(uint32_t nblk, uint32_t list_size, uint32_t max_dev) const {
-  const double entry = 4.0 + 4.0 * msg_words();
-  std::vector<uint64_t> prefix(npos + 1, 0);
-  for (uint32_t p = 0; p < npos; ++p) prefix[p + 1] = prefix[p] + reach_per_pos[p];
+// The band of time step t the kernels work on: the reference's (:677-679, Code::band) without the positions whose lists
+// cannot matter.
+//  * A path advances at most one position per time step, so after step t only positions <= t + 1 hold a finite score: the
+//    reference writes -inf lists above (:799), the kernels neither write nor read them -- the band ends at t + 2 for them, and
+//    "beyond the previous band end" already reads as -inf (the upper band edge).  3.8 % of a read's (step, position) pairs.
+//  * A state at position p after step t can still reach the final position only if p >= npos - nblk + t; states below feed
+//    nothing that the final selection (:806-824) reads -- a state's predecessors lie one position lower or one step earlier, so
+//    states that matter depend on states that matter only -- and are neither written nor read: the band starts there.  1.2 %.
+// (tests/test_host_logic.py checks both against a reachability computation on the reference's band.)
+void Code::working_band(uint32_t t, uint32_t nblk, uint32_t max_dev, uint32_t* lo_out, uint32_t* hi_out) const {
+  uint32_t lo, hi;
+  band(t, nblk, max_dev, &lo, &hi);
+  hi = std::min<uint32_t>(hi, t + 2);
+  const int64_t alive = (int64_t)npos - (int64_t)nblk + (int64_t)t;
+  if (alive > (int64_t)lo) lo = (uint32_t)std::min<int64_t>(alive, hi);
+  *lo_out = lo; *hi_out = hi;
+}
+
+static double band_bytes(const Code& c, uint32_t nblk, uint32_t list_size, uint32_t max_dev, bool working) {
+  const double entry = 4.0 + 4.0 * c.msg_words();
+  std::vector<uint64_t> prefix(c.npos + 1, 0);
+  for (uint32_t p = 0; p < c.npos; ++p) prefix[p + 1] = prefix[p] + c.reach_per_pos[p];
   double total = 0;
   for (uint32_t t = 0; t < nblk; ++t) {
     uint32_t lo, hi;
-    band(t, nblk, max_dev, &lo, &hi);
+    if (working) c.working_band(t, nblk, max_dev, &lo, &hi); else c.band(t, nblk, max_dev, &lo, &hi);
     const uint64_t R = hi > lo ? prefix[hi] - prefix[lo] : 0;
     total += 2.0 * (double)R * list_size * entry + 160.0;
   }
   return total;
 }
+
+double Code::algorithmic_bytes(uint32_t nblk, uint32_t list_size, uint32_t max_dev) const { return band_bytes(*this, nblk, list_size, max_dev, false); }
+double Code::working_bytes(uint32_t nblk, uint32_t list_size, uint32_t max_dev) const { return band_bytes(*this, nblk, list_size, max_dev, true); }
 
 }  // namespace lva

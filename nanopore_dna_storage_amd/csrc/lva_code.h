@@ -57,6 +57,10 @@ struct Code {
   void band(uint32_t t, uint32_t nblk, uint32_t max_dev, uint32_t* lo, uint32_t* hi) const;
   // algorithmic bytes of one read: sum_t [2*R(t)*L*(4+4W) + 160]
   double algorithmic_bytes(uint32_t nblk, uint32_t list_size, uint32_t max_dev) const;
+  // the same sum over the band the kernels work on (the reference's without the positions a path cannot have reached yet and
+  // the positions that cannot reach the final one any more): what bench.py calls `frac_moved`
+  double working_bytes(uint32_t nblk, uint32_t list_size, uint32_t max_dev) const;
+  void working_band(uint32_t t, uint32_t nblk, uint32_t max_dev, uint32_t* lo, uint32_t* hi) const;
 };
 
 // set_conv_params (:264-415).  Returns 0 or a negative LVA_ERR_* code (include/lva_decoder.h).

@@ -107,31 +107,71 @@ def decode_rows(args, rows, dec):
     return results, located
 
 
-def write_list_file(path, msgs):
-    """one decoded list, written to a temporary name and moved into place: a run killed in the middle never leaves
-    a truncated OUT_PREFIX_i that --resume would take for a finished read"""
-    d, base = os.path.split(path)
-    tmp = os.path.join(d, TMP_PREFIX + base + "-%d" % os.getpid())     # never matches OUT_PREFIX_<i> (list consumers take every list_*)
-    with open(tmp, "w") as f:
-        for row in msgs:
-            f.write("".join("1" if b else "0" for b in row) + "\n")
-        f.flush()
-        os.fsync(f.fileno())                     # the rename must not become durable before the data
-    os.replace(tmp, path)
-
-
 TMP_PREFIX = ".tmp-"
 
 
+def write_list_temp(path, msgs):
+    """one decoded list under a temporary name beside its final one (never matches OUT_PREFIX_<i>: list consumers take every
+    list_*); publish_list_files moves a whole chunk's files into place.  -> (temporary name, final name)"""
+    d, base = os.path.split(path)
+    tmp = os.path.join(d, TMP_PREFIX + base + "-%d" % os.getpid())
+    with open(tmp, "w") as f:
+        for row in msgs:
+            f.write("".join("1" if b else "0" for b in row) + "\n")
+    return tmp, path
+
+
+def publish_list_files(pairs):
+    """A chunk's list files become visible under their final names only after their data is durable: a run killed in the middle
+    never leaves a truncated OUT_PREFIX_i that --resume would take for a finished read.  Durability is paid once per chunk --
+    every file is written first, then flushed (after the first flush has committed the journal the others find nothing left
+    to write), then renamed, then the directory is flushed -- not one write barrier per read: on small trellises the decoder
+    produces thousands of lists a second (the reference never flushes at all)."""
+    for tmp, _ in pairs:
+        fd = os.open(tmp, os.O_RDONLY)
+        try:
+            os.fsync(fd)                         # the rename must not become durable before the data
+        finally:
+            os.close(fd)
+    for tmp, path in pairs:
+        os.replace(tmp, path)
+    for d in {os.path.dirname(path) or "." for _, path in pairs}:
+        fd = os.open(d, os.O_RDONLY)
+        try:
+            os.fsync(fd)
+        finally:
+            os.close(fd)
+
+
+def write_list_file(path, msgs):
+    """one decoded list, durable before it is visible (a chunk of them: write_list_temp + publish_list_files)"""
+    publish_list_files([write_list_temp(path, msgs)])
+
+
 def remove_stale_temp_files(out_prefix):
-    """temporary list files a killed run left behind (start-up of every run)"""
+    """temporary list files a killed run left behind (start-up of every run): exactly the names write_list_temp makes for THIS
+    prefix -- .tmp-<base>_<i>-<pid>, so that a run on prefix `list` leaves `list_b`'s files alone -- and only when the process
+    that made them is gone (a concurrent run on the same prefix may be alive)."""
+    import re
     d, base = os.path.split(out_prefix)
+    pat = re.compile(re.escape(TMP_PREFIX + base) + r"_\d+-(\d+)$")
     for name in os.listdir(d or "."):
-        if name.startswith(TMP_PREFIX + base + "_"):
+        mt = pat.match(name)
+        if not mt:
+            continue
+        pid = int(mt.group(1))
+        if pid != os.getpid():
             try:
-                os.remove(os.path.join(d or ".", name))
-            except OSError:
+                os.kill(pid, 0)                  # (signal 0: existence check only)
+                continue                         # its writer is alive
+            except ProcessLookupError:
                 pass
+            except PermissionError:
+                continue                         # alive, another user's
+        try:
+            os.remove(os.path.join(d or ".", name))
+        except OSError:
+            pass
 
 
 def run(args, out=sys.stdout, dist=None, device=None, coll_dev=None):
@@ -153,6 +193,7 @@ def run(args, out=sys.stdout, dist=None, device=None, coll_dev=None):
 
     def report(upto, results, loc):
         nonlocal cursor, written
+        pending = []                                       # this chunk's list files, published together
         for i in range(cursor, upto):
             rid, ref = rows[i][0], rows[i][1]
             print("i:", i, file=out); print(rid, file=out); print(ref, file=out)
@@ -167,8 +208,9 @@ def run(args, out=sys.stdout, dist=None, device=None, coll_dev=None):
                 if r == BARCODE_FAILURE:
                     print("Failure in barcode removing.", file=out)
                 continue       # (other codes: the reference decoder aborts, no output file, on such a read)
-            write_list_file(args.out_prefix + "_" + str(i), r[0])
+            pending.append(write_list_temp(args.out_prefix + "_" + str(i), r[0]))
             written += 1
+        publish_list_files(pending)
         cursor = max(cursor, upto)
         f_info.flush()
 

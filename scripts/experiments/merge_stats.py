@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Merge statistics of the list decoder (kernel design input): builds scripts/merge_stats_oracle.c -- an INSTRUMENTED
+"""Merge statistics of the list decoder (kernel design input): builds scripts/experiments/merge_stats_oracle.c -- an INSTRUMENTED
 COPY of the CPU oracle (the pinned oracle/lva_oracle.c itself carries no bookkeeping) -- with -DLVA_ORACLE_STATS into /tmp
 and prints, for one synthetic read, how many heap pops a target
 needs and how deep each candidate list is consumed.
@@ -13,7 +13,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from nanopore_dna_storage_amd import synth  # noqa: E402
 
@@ -22,7 +22,7 @@ margin = float(sys.argv[5]) if len(sys.argv) > 5 else 4.0
 thr = int(sys.argv[6]) if len(sys.argv) > 6 else 4
 so = "/tmp/liblva_oracle_stats.so"
 subprocess.run(["gcc", "-O2", "-std=c11", "-fopenmp", "-fPIC", "-shared", "-fno-fast-math", "-ffp-contract=off",
-                "-DLVA_ORACLE_STATS", "-I", os.path.join(ROOT, "oracle"), "-o", so, os.path.join(ROOT, "scripts", "merge_stats_oracle.c"),
+                "-DLVA_ORACLE_STATS", "-I", os.path.join(ROOT, "oracle"), "-o", so, os.path.join(ROOT, "scripts", "experiments", "merge_stats_oracle.c"),
                 os.path.join(ROOT, "oracle", "basecall_oracle.c"), "-lm"], check=True)
 Lb = ctypes.CDLL(so)
 Lb.lva_oracle_code_new.restype = ctypes.c_void_p

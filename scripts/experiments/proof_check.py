@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Checks the rule by which the lazy kernels call a duplicate PROVEN without comparing messages on the CPU:
-builds scripts/proof_check_oracle.c (an instrumented copy of the oracle) into /tmp, decodes synthetic reads and prints
+builds scripts/experiments/proof_check_oracle.c (an instrumented copy of the oracle) into /tmp, decodes synthetic reads and prints
   pairs      (stay entry, source entry) pairs of all targets on which the rule fires -- whatever their fingerprints
   violations of those, pairs whose messages differ            -- MUST BE 0
   dups       duplicate rejections of the reference merge; how many pair a stay entry with a source entry; how many the rule covers
@@ -14,7 +14,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from nanopore_dna_storage_amd import synth  # noqa: E402
 
@@ -23,7 +23,7 @@ n = int(sys.argv[5]) if len(sys.argv) > 5 else 3
 md = int(sys.argv[6]) if len(sys.argv) > 6 else 20
 so = "/tmp/liblva_proof_check.so"
 subprocess.run(["gcc", "-O2", "-std=c11", "-fopenmp", "-fPIC", "-shared", "-fno-fast-math", "-ffp-contract=off", "-I", os.path.join(ROOT, "oracle"),
-                "-o", so, os.path.join(ROOT, "scripts", "proof_check_oracle.c"), os.path.join(ROOT, "oracle", "basecall_oracle.c"), "-lm"], check=True)
+                "-o", so, os.path.join(ROOT, "scripts", "experiments", "proof_check_oracle.c"), os.path.join(ROOT, "oracle", "basecall_oracle.c"), "-lm"], check=True)
 Lb = ctypes.CDLL(so)
 Lb.lva_oracle_code_new.restype = ctypes.c_void_p
 Lb.lva_oracle_code_new.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_char_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_int)]

@@ -188,7 +188,7 @@ def test_list_decode_with_crc_index_filter(oracle):
     lists = [["".join(map(str, row)) for row in g[0]] for g in got]
     want = []
     for post, rc in reads:
-        wm, _ = oracle.OracleCode(8, 3, 164, rc=rc).decode(post, L, 20, num_threads=8)
+        wm, _ = oracle.OracleCode(8, 3, 164, rc=rc).decode(post, L, 20, num_threads=32)
         want.append(["".join(map(str, row)) for row in wm])
     assert lists == want
     t = helper.tally_decoded_lists(lists, conv_in, bytes_per_oligo, False, L)

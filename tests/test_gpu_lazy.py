@@ -20,7 +20,7 @@ def _compare(oracle, m, r, msg_len, L, md, reads, max_slots=0, sync_marker="", s
         got = dec.decode([x["post"] for x in reads], rc=[x["rc"] for x in reads])
     for i, (x, g) in enumerate(zip(reads, got)):
         code = oracle.OracleCode(m, r, msg_len, rc=x["rc"], sync_marker=sync_marker, sync_period=sync_period)
-        want_msgs, want_scores = code.decode(x["post"], L, md, num_threads=8)
+        want_msgs, want_scores = code.decode(x["post"], L, md, num_threads=16)
         assert not isinstance(g, int), "read %d: error %r" % (i, g)
         assert np.array_equal(g[1].view(np.uint32), want_scores.view(np.uint32)), "read %d: scores differ" % i
         assert np.array_equal(g[0], want_msgs), "read %d (nblk %d): list differs" % (i, x["post"].shape[0])

@@ -41,7 +41,7 @@ def test_random_case(oracle, case):
     for x, g in zip(reads, got):
         code = oracle.OracleCode(m, r, msg_len, rc=x["rc"])
         try:
-            wm, ws = code.decode(x["post"], L, md, num_threads=4)
+            wm, ws = code.decode(x["post"], L, md, num_threads=16)
         except oracle.OracleError as e:
             assert g == e.status
             continue

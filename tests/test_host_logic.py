@@ -233,13 +233,19 @@ def test_list_files_are_written_atomically(tmp_path):
     assert [f.name for f in tmp_path.iterdir()] == ["list_7"]
     # a temporary file a killed run left behind never looks like a list file (list consumers take list_<digits> only) and is
     # removed by the next run
-    stale = tmp_path / (gdl.TMP_PREFIX + "list_9-12345")
+    import subprocess
+    dead = subprocess.Popen(["true"]); dead.wait()                     # a process id that no longer exists
+    stale = tmp_path / (gdl.TMP_PREFIX + "list_9-%d" % dead.pid)
     stale.write_text("10")
+    other = tmp_path / (gdl.TMP_PREFIX + "list_b_3-%d" % dead.pid)     # another prefix that shares the stem: not ours to delete
+    other.write_text("10")
+    alive = tmp_path / (gdl.TMP_PREFIX + "list_4-%d" % os.getppid())   # a concurrent run on the same prefix (its writer is alive)
+    alive.write_text("10")
     from nanopore_dna_storage_amd import compute_error_rate_from_decoded_lists as cer
     (tmp_path / "list_7.bak").write_text("1\n")
     assert [n for n, _ in cer.read_lists(str(tmp_path))] == ["list_7"]
     gdl.remove_stale_temp_files(str(tmp_path / "list"))
-    assert not stale.exists() and p.exists()
+    assert not stale.exists() and p.exists() and other.exists() and alive.exists()
     args = gdl.build_parser().parse_args(["--post_manifest", "m", "--out_prefix", "o", "--info_file", "i", "--mem_conv", "6", "--msg_len", "60",
                                           "--rate_conv", "1", "--list_size", "4"])
     assert args.chunk == 4096 and args.max_deviation == 20 and args.gpus == 1
@@ -277,5 +283,24 @@ def test_working_band_keeps_every_state_that_can_matter(oracle, m, r, msg_len, m
         for t in range(nblk):
             p = np.nonzero(need[t])[0]
             assert p.size == 0 or (work[t, 0] <= p.min() and p.max() < work[t, 1]), (nblk, t, p.min(), p.max(), work[t])
+        # The stale row: the buffers are never cleared, so the lowest band position p = lo(t) reads row p - 1 of the
+        # other parity buffer as it was LAST written -- at step t - 1 if the band held p - 1 then, else at the last step t' of
+        # t - 1's parity whose band did.  The kernels walk the working band: wherever the consumer cell can matter, the row they
+        # find must have been written by the same step as the reference's, or hold nothing in the reference either (a position
+        # no path had reached when it was written: -inf lists, which the kernels neither write nor read).
+        def last_writer(band, t, pos):
+            for tt in range(t - 1, -1, -2):
+                if band[tt, 0] <= pos < band[tt, 1]:
+                    return tt
+            return None
+        for t in range(1, nblk):
+            pw = int(work[t, 0])
+            if pw < 1 or pw >= work[t, 1] or not need[t, pw]:
+                continue
+            t_ref, t_k = last_writer(ref, t, pw - 1), last_writer(work, t, pw - 1)
+            if t_ref is None:
+                assert t_k is None
+            elif t_k != t_ref:
+                assert t_k is None and pw - 1 > t_ref + 1, (nblk, t, pw, t_ref, t_k)
         # and it really is smaller where it can be
         assert work[0, 1] <= 2 and work[nblk - 1, 0] >= min(npos - 1, ref[nblk - 1, 1])

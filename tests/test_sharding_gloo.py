@@ -135,3 +135,53 @@ def test_forced_group_of_one_runs_the_collectives(tmp_path):
     posts, rc = W.fake_posts(9)
     c, m, s = sharding.pack_results(W.fake_decode(posts, rc), W.L, W.MSG)
     assert np.array_equal(z["counts"], c) and np.array_equal(z["msgs"], m) and np.array_equal(z["scores"], s)
+
+
+def test_launch_ranks_world8_uneven_shards_and_error_codes(tmp_path):
+    """Eight ranks (the node the driver's scaling run uses; gloo here): 67 = 8 * 8 + 3 reads in strided shards of 9 and 8, reads
+    too short to decode (error codes instead of lists) in several shards; rank 0's gathered list equals the single-process result
+    in input order (util/extra/merge_lists.py:11-21)."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    import _rank_worker as W
+    n, world = 67, 8
+    posts, rc = W.fake_posts(n)
+    want = W.fake_decode(posts, rc)
+    shards = sharding.shard_strided(n, world)
+    assert sorted(len(s) for s in shards) == [8] * 5 + [9] * 3
+    bad_ranks = {r for r, s in enumerate(shards) for i in s if isinstance(want[int(i)], int)}
+    assert len(bad_ranks) >= 2, "the fixture should put error-coded reads into several ranks"
+    out = str(tmp_path / "g8.npz")
+    env = dict(os.environ, LVA_DIST_BACKEND="gloo")
+    assert sharding.launch_ranks(os.path.join(here, "_rank_worker.py"), [out, "fake", str(n)], world, env=env) == 0
+    z = np.load(out)
+    assert int(z["world"]) == world
+    c, m, s = sharding.pack_results(want, W.L, W.MSG)
+    assert np.array_equal(z["counts"], c) and np.array_equal(z["msgs"], m) and np.array_equal(z["scores"], s)
+    assert (z["counts"] < 0).sum() == sum(isinstance(w, int) for w in want) > 0
+
+
+def test_bench_eight_ranks_strong_scaling_arguments(tmp_path):
+    """`bench.py --gpus 8 --total-reads 100000` -- the driver's configs[2] run -- with a stand-in decoder (LVA_BENCH_STUB, honoured
+    only with LVA_TESTING): self-launch of eight ranks, strided shards of 12 500 reads, the clock's all_reduce, the per_rank
+    all_gather, the gather of 100 000 lists on rank 0 and the JSON line, without a GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LVA_BENCH_BACKEND="gloo", LVA_BENCH_STUB="1", LVA_TESTING="1", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    dump = str(tmp_path / "lists.npz")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--total-reads", "100000", "--steps", "1", "--warmup", "0",
+                        "--list-size", "4", "--msg-len", "12", "--no-cross-check", "--dump-lists", dump],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    j = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["n_gpus"] == 8 and j["scaling"] == "strong" and j["config"]["gathered_lists"] == 100000
+    assert len(j["config"]["per_rank"]) == 8 and [r["rank"] for r in j["config"]["per_rank"]] == list(range(8))
+    assert j["config"]["reads_per_step_per_gpu"] == 12500 and j["config"]["dist_backend"] == "gloo"
+    z = np.load(dump)
+    n = np.array([3 + (gi * 7919) % 57 for gi in range(100000)])                   # the stand-in reads' block counts
+    assert np.array_equal(z["counts"], np.where(n < 5, -6, 1 + n % 4))             # every list in global read order, error codes too
