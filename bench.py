@@ -224,10 +224,13 @@ def main():
     acc = dict(span_ms=0.0, dom_ms=0.0, pair_ms=0.0, alg=0.0, moved=0.0, launches=0, tl=0, read_steps=0, fix=0, h2d_ms=0.0, h2d_b=0,
                total_ms=0.0)
     fixr = [0, 0, 0, 0]
+    step_ms = []                                    # this rank's wall time of every timed step (drift over a long run shows here)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         b = step_no % nbatch
+        ts = time.perf_counter()
         outs[b] = run(batches[b]); step_no += 1     # returns after the stream is drained and the lists are on the host
+        step_ms.append(1e3 * (time.perf_counter() - ts))
         p = dec.profile()
         acc["span_ms"] += p["step_kernel_ms"]; acc["dom_ms"] += p["dominant_kernel_ms"]; acc["pair_ms"] += p["step_pair_ms"]
         acc["alg"] += p["algorithmic_bytes"]; acc["moved"] += p["working_bytes"]; acc["launches"] += p["step_launches"]; acc["tl"] += p["timed_launches"]
@@ -286,7 +289,7 @@ def main():
                        "kernel": prof["kernel"], "fixup_states": acc["fix"], "fixup_reason": fixr,
                        "gathered_lists": n_global, "mean_active_slots": acc["read_steps"] / max(acc["launches"], 1),
                        "dist_backend": dist.get_backend() if dist is not None else None, "world": world,
-                       "per_rank": per_rank},
+                       "per_rank": per_rank, "step_ms_rank0": [round(x, 1) for x in step_ms]},
             # the library that was measured: lva_version() carries a hash of its source files (csrc/Makefile); counter files
             # under profiles/ name the build they were taken on, and `traffic` below is only filled from a file of THIS build
             "library": {"version": L.lva_version().decode(), "build_id": build_id},

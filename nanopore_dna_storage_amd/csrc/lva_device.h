@@ -122,10 +122,10 @@ struct Geometry {                // strides in 32-bit words
                                  // Readers stage 4 x L rows of such a source position, all of them data, instead of 8 x L rows of which
                                  // half is never-written memory interleaved at conv-state granularity
   uint32_t rec;                  // big-list kernel, three message planes, L >= 32 and a multiple of 4: RECORD layout.  A (ring, crf) list is
-                                 //   [conv N][entry L][8 words: score, fingerprint, message words 4-5, message words 0-3]
+                                 //   [conv N][entry L][2 + 2 np words: score, fingerprint, the 2 np message words in use at the position]
                                  // instead of L blocks of conv-fastest planes: the entries of one conv state's list are adjacent
-                                 // (4 per 128-byte line), so a thread that walks a list pulls each line once instead of one line
-                                 // per entry, and an entry is one line instead of three (same footprint: sCrf = N*L*8 words)
+                                 // (4 to 8 per 128-byte line), so a thread that walks a list pulls each line once instead of one line
+                                 // per entry, and an entry is one line instead of three (allocated for np = 3: sCrf = N*L*8 words)
   uint64_t sCrf, sRing, sPar, sSlot;
 };
 

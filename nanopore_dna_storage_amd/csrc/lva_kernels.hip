@@ -22,7 +22,7 @@
 //   lva_step_fast<L,P> + lva_step_fixup   the same tile with messages moved on every step (kernel mode 2 at L = 2/4/8).
 //   lva_step_acs<P>  L = 1: plain add-compare-select on the same tile, 256 threads.
 //   lva_step_big<LL,P> / lva_step_big_rec<LL> + lva_step_fixup_wave   other list sizes up to 64: list heads read on
-//                    demand; plane layout / record layout (Geometry::rec).
+//                    demand; plane layout / record layout (Geometry::rec: records of 16, 24 or 32 bytes by trellis position).
 //   lva_step_wave    the literal merge with one wavefront per target over the whole step (kernel mode 3).
 //   lva_step_exact   one thread per target state, the same literal merge straight from HBM -- any list size; kernel
 //                    mode 1, the default above 64 entries, and the overflow path of lva_step_fixup.
@@ -30,6 +30,8 @@
 //   lva_init_slot    initial scores (:657-663)
 //   lva_gather_final final state's lists -> result record (:806-815)
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 #include "lva_device.h"
 #include "lva_kernels.h"
@@ -228,13 +230,15 @@ __device__ __forceinline__ uint32_t msg_word(const Geometry& g, const uint32_t* 
 
 // Either layout (Geometry::rec, lva_device.h): entry l of conv state c of the list that starts at word `list`.
 //   rec_sh    word offset of its (score, fingerprint) pair
-//   rec_word  word offset of its message word w (np = planes in use at the entry's position; the record layout carries all six)
-// Record = 8 words: score, fingerprint, message words 4-5, message words 0-3.
-__device__ __forceinline__ uint32_t rec_sh(const Geometry& g, uint32_t list, uint32_t c, uint32_t l) {
-  return g.rec ? list + (c * g.L + l) * 8u : list + l * g.sBlk + 2 * c;
+//   rec_word  word offset of its message word w
+// np = message planes in use at the list's trellis position.  Record layout: a list is [conv][entry] records of 2 + 2 np words --
+// score, fingerprint, the 2 np message words in use there, least significant first: 16, 24 or 32 bytes per entry, so that a
+// position in the first third of a read moves half the bytes of one in the last third (as the plane layout does with its planes).
+__device__ __forceinline__ uint32_t rec_sh(const Geometry& g, uint32_t list, uint32_t c, uint32_t l, uint32_t np) {
+  return g.rec ? list + (c * g.L + l) * (2u + 2u * np) : list + l * g.sBlk + 2 * c;
 }
 __device__ __forceinline__ uint32_t rec_word(const Geometry& g, uint32_t list, uint32_t c, uint32_t l, uint32_t w, uint32_t np) {
-  return g.rec ? list + (c * g.L + l) * 8u + (w < 4 ? 4u + w : w - 2u) : list + l * g.sBlk + 2 * g.N + msg_word_off(g.N, c, w, np);
+  return g.rec ? list + (c * g.L + l) * (2u + 2u * np) + 2u + w : list + l * g.sBlk + 2 * g.N + msg_word_off(g.N, c, w, np);
 }
 // message word w of that entry; words in planes that are not in use at the entry's position are zero
 __device__ __forceinline__ uint32_t entry_word(const Geometry& g, const uint32_t* __restrict__ buf, uint32_t list, uint32_t c, uint32_t l,
@@ -665,14 +669,14 @@ __device__ __forceinline__ void wave_target(const Geometry& g, const SlotStep& s
   const uint32_t L = g.L, sBlk = g.sBlk, sCrf = (uint32_t)g.sCrf;
   const uint32_t Wd = 2 * tg.np_dst;
   const float NEG = -INFINITY;
-  const uint32_t own_sh = rec_sh(g, tg.own, tg.c, 0);
+  const uint32_t own_sh = rec_sh(g, tg.own, tg.c, 0, tg.np_dst);
   if (pos == 0) {                                                      // :706-713
     if (lane == 0) {
       cur[own_sh] = f2u(u2f(prev[own_sh]) + ss.post_row[tg.row * 8 + k]);
       cur[own_sh + 1] = prev[own_sh + 1];
     }
-    if (lane < (g.rec ? 6u : Wd)) cur[rec_word(g, tg.own, tg.c, 0, lane, tg.np_dst)] = prev[rec_word(g, tg.own, tg.c, 0, lane, tg.np_dst)];
-    if (lane >= 1 && lane < L) cur[rec_sh(g, tg.own, tg.c, lane)] = kNegInfBits;
+    if (lane < Wd) cur[rec_word(g, tg.own, tg.c, 0, lane, tg.np_dst)] = prev[rec_word(g, tg.own, tg.c, 0, lane, tg.np_dst)];
+    if (lane >= 1 && lane < L) cur[rec_sh(g, tg.own, tg.c, lane, tg.np_dst)] = kNegInfBits;
     return;
   }
   auto rdf = [](float v, uint32_t ln) -> float { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)ln)); };
@@ -685,7 +689,7 @@ __device__ __forceinline__ void wave_target(const Geometry& g, const SlotStep& s
   for (uint32_t i = 0; i < 8; ++i) {
     cs[i] = NEG; cy[i] = 0;
     if (i < tg.nlists && ((tg.okmask >> i) & 1u) && lane < L) {
-      const uint32_t b = rec_sh(g, i == 0 ? tg.own : tg.src + list_crf(k, i) * sCrf, i == 0 ? tg.c : tg.cp, lane);
+      const uint32_t b = rec_sh(g, i == 0 ? tg.own : tg.src + list_crf(k, i) * sCrf, i == 0 ? tg.c : tg.cp, lane, i == 0 ? tg.np_dst : tg.np_src);
       const uint2 v = *reinterpret_cast<const uint2*>(prev + b);
       cs[i] = u2f(v.x); cy[i] = i != 0 ? v.y ^ tg.fpc : v.y;
     }
@@ -779,21 +783,25 @@ __device__ __forceinline__ void wave_target(const Geometry& g, const SlotStep& s
   }
   // 3. outputs: lane a writes list entry a (:781, :799) and, if accepted, its message
   if (lane < L) {
-    *reinterpret_cast<uint2*>(cur + rec_sh(g, tg.own, tg.c, lane)) = lane < l ? make_uint2(f2u(as), ay) : make_uint2(kNegInfBits, 0u);
+    *reinterpret_cast<uint2*>(cur + rec_sh(g, tg.own, tg.c, lane, tg.np_dst)) = lane < l ? make_uint2(f2u(as), ay) : make_uint2(kNegInfBits, 0u);
     if (lane < l) {          // the whole message in the widest pieces the layout has (not word by word: every access of a lane is its own line)
       const uint32_t li = ax >> 16, lj = ax & 0xFFFFu;
       const uint32_t lst = li == 0 ? tg.own : tg.src + list_crf(k, li) * sCrf, cv = li == 0 ? tg.c : tg.cp;
       uint32_t m[8];
-      if (g.rec) {           // record layout: all six words of every stored entry are valid (zero in planes not yet in use)
-        const uint32_t* rp = prev + rec_sh(g, lst, cv, lj);
-        const lva_u32x4 lo = *LVA_GLOBAL(lva_u32x4, rp + 4);
-        const lva_u32x2 hi = *LVA_GLOBAL(lva_u32x2, rp + 2);
-        m[0] = lo.x; m[1] = lo.y; m[2] = lo.z; m[3] = lo.w; m[4] = hi.x; m[5] = hi.y; m[6] = 0; m[7] = 0;
+      if (g.rec) {           // record layout: the words in use at the entry's position follow its (score, fingerprint) pair
+        const uint32_t npi = li == 0 ? tg.np_dst : tg.np_src;
+        const uint32_t* rp = prev + rec_sh(g, lst, cv, lj, npi) + 2;
+#pragma unroll
+        for (uint32_t q2 = 0; q2 < 4; ++q2) {
+          lva_u32x2 v = {0u, 0u};
+          if (q2 < npi) v = *LVA_GLOBAL(lva_u32x2, rp + 2 * q2);
+          m[2 * q2] = v.x; m[2 * q2 + 1] = v.y;
+        }
         push_bits<8>(m, li == 0 ? 0u : tg.shift, tg.newbits);
-        uint32_t* wp = cur + rec_sh(g, tg.own, tg.c, lane);
-        const lva_u32x4 out = {m[0], m[1], m[2], m[3]};
-        *reinterpret_cast<lva_u32x4*>(wp + 4) = out;
-        wp[2] = m[4]; wp[3] = m[5];
+        uint32_t* wp = cur + rec_sh(g, tg.own, tg.c, lane, tg.np_dst) + 2;
+#pragma unroll
+        for (uint32_t q2 = 0; q2 < 4; ++q2)
+          if (q2 < tg.np_dst) *reinterpret_cast<lva_u32x2*>(wp + 2 * q2) = lva_u32x2{m[2 * q2], m[2 * q2 + 1]};
       } else {
         load_msg<4>(prev + lst + lj * sBlk + 2 * g.N, g.N, cv, li == 0 ? tg.np_dst : tg.np_src, m);
         push_bits<8>(m, li == 0 ? 0u : tg.shift, tg.newbits);
@@ -2046,21 +2054,23 @@ __global__ __launch_bounds__(8 * TSB) void lva_step_big(StepArgs args, Geometry 
 
 
 // ---------------------------------------------------------------------------------------
-// Big-list kernel on the RECORD layout (Geometry::rec: three message planes, L a multiple of 4).
+// Big-list kernel on the RECORD layout (Geometry::rec: three message planes, 32 <= L <= 64, L a multiple of 4).
 //
-// What bounds lva_step_big is the number of cache lines it pulls, not instructions and not latency: per target and step
-// ~80 list heads + 64 re-reads of accepted (score, fingerprint) pairs + 128 message pieces, each an 8- or 16-byte access
-// to its own line of a conv-fastest row -- rocprofv3 (round 3): 2.8x the algorithmic bytes at ~5.7 TB/s.  Every variant
-// that changed the number of operations without changing the number of lines lost (16-byte units, 16-conv tiles,
-// non-temporal message loads, more workgroups per CU: round 4).  Here the entries of ONE conv state's list are adjacent
-// -- [conv][entry][score, fingerprint, words 4-5, words 0-3], four records per 128-byte line -- so
+// A (ring, crf) list is [conv][entry] records of 2 + 2 np words -- score, fingerprint, the 2 np message words in use at the
+// list's trellis position (np = 1, 2, 3: 16, 24, 32 bytes; a position in the first third of a read moves half the bytes of
+// one in the last third) -- so the entries of ONE conv state's list are adjacent:
 //   * a thread that walks a list (the merge pops ~46 of a target's 64 entries from one source list) pulls a line per
-//     four entries instead of one per entry;
-//   * an accepted entry is ONE line (two 16-byte loads: score and fingerprint come with the message) instead of three;
-//   * a target's output is 2 KB contiguous.  Threads cannot store it themselves (64 partial lines per instruction:
-//     measured 1.6x slower in round 2): each wavefront passes four entries of its 64 targets through LDS and stores
-//     whole 128-byte lines, eight targets per instruction.  For that the wavefront stays whole: threads without a target,
-//     and threads whose target goes to the work list, keep running as store helpers.
+//     four to eight entries instead of one per entry, and the lines it pulls are the ones the output phase needs (a packed copy
+//     of the pairs for the walk made the output's gathers cold and the kernel 22 % slower: round 5);
+//   * an accepted entry is ONE line (one or two loads: score and fingerprint come with the message) instead of three;
+//   * a target's output is contiguous.  Threads cannot store it themselves (64 partial lines per instruction: measured 1.6x
+//     slower in round 2; an 8-byte store per lane and round inside the merge loop wrote 12.5 GB instead of 7.4: round 5): each
+//     wavefront passes four entries of its 64 targets through LDS and stores runs of 64 / 96 / 128 bytes per target, 16 bytes
+//     per lane.  For that the wavefront stays whole: threads without a target, and threads whose target goes to the work list,
+//     keep running as store helpers.
+//   * The output phase requests the four records of a round with ALL lanes, in straight-line code, before it waits for any: a
+//     load behind a per-lane branch has an unknown place in the memory queue and the compiler then waits for everything
+//     (s_waitcnt vmcnt(0)) in front of the next write to its register -- four round trips per round instead of one (round 5).
 // One fingerprint-match slot per accepted entry (a second match is reason 3: the exact path decides).
 // Same decisions as big_merge otherwise; ties, non-finite sums and collisions go to lva_step_fixup_wave, which reads and
 // writes the same layout (rec_sh / rec_word).
@@ -2068,18 +2078,23 @@ __global__ __launch_bounds__(8 * TSB) void lva_step_big(StepArgs args, Geometry 
 namespace {
 
 constexpr uint32_t kTrRow = 36;      // words per thread in the transpose buffer: 4 records + 4 words of padding (conflict-free b128)
+typedef unsigned int lva_u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));   // 16 bytes at an 8-byte aligned address (24-byte records)
 
 template <int LL, int NL>
 __device__ __forceinline__ int big_merge_rec(const Geometry& g, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur,
                                               const float* s_post, uint8_t* s_acc, uint8_t* s_rej0, uint32_t* s_tr, uint32_t* s_base,
-                                              bool valid, const TileTarget& t, uint32_t src) {
+                                              bool valid, const TileTarget& t, uint32_t src, uint32_t npd, uint32_t nps) {
   constexpr uint32_t NT = 8 * TSB;
   const float NEG = -INFINITY;
   const uint32_t L = g.L, sCrf = (uint32_t)g.sCrf;
   const uint32_t lane = threadIdx.x & 63u, wrow = threadIdx.x & ~63u;     // first thread of this wavefront
   const uint32_t k = t.k, row = k >= 4 ? 4u : k;
-  const uint32_t own_r = t.own + mul24(t.c, L) * 8u, src_r = src + mul24(t.cp, L) * 8u;   // record 0 of the own / of a source list 0
+  // records of 2 + 2 np words: np = message planes in use at the list's position -- the own (stay) list lives at pos, the source
+  // lists at pos - 1 (one plane less at the two or three positions where the message crosses a multiple of 64 bits)
+  const uint32_t rws = 2u + 2u * nps, rwd = 2u + 2u * npd;     // (npd, nps: from the position record, uniform over the workgroup)
+  const uint32_t own_r = t.own + mul24(t.c, L) * rwd, src_r = src + mul24(t.cp, L) * rws;   // record 0 of the own / of a source list 0
   auto lrec = [&](uint32_t i) -> uint32_t { return i == 0 ? own_r : src_r + mul24(list_crf(k, i), sCrf); };
+  auto lrw = [&](uint32_t i) -> uint32_t { return i == 0 ? rwd : rws; };
   auto ladd = [&](uint32_t i) -> float { return s_post[row * 8 + (i == 0 ? k : list_crf(k, i))]; };
   int why = 0;
   uint32_t lc = 0;
@@ -2161,7 +2176,7 @@ __device__ __forceinline__ int big_merge_rec(const Geometry& g, const uint32_t* 
       const uint32_t j = (uint32_t)(ptr >> (7 * sel)) & 127u;
       // next entry of the popped list -- the neighbouring record: requested now, used after the scan (:788-796)
       const bool has_next = j + 1 < L;
-      const lva_u32x2 nv = *LVA_GLOBAL(lva_u32x2, prev + lrec(sel) + (has_next ? j + 1 : j) * 8u);
+      const lva_u32x2 nv = *LVA_GLOBAL(lva_u32x2, prev + lrec(sel) + mul24(has_next ? j + 1 : j, lrw(sel)));
       uint32_t ch = hf[NL - 1];
 #pragma unroll
       for (int i = NL - 2; i >= 0; --i) ch = selv(eq[i], hf[i], ch);
@@ -2187,89 +2202,117 @@ __device__ __forceinline__ int big_merge_rec(const Geometry& g, const uint32_t* 
   auto locate = [&](uint32_t from9, uint32_t* i_out) -> uint32_t {   // record of entry `from9` of the previous step
     const uint32_t i = from9 >> 6, j = from9 & 63u;
     *i_out = i;
-    return lrec(i) + j * 8u;
+    return lrec(i) + mul24(j, lrw(i));
   };
   bool good = true;
   // the transpose buffer holds the four records of HALF a wavefront's targets (32 rows per wavefront): 51 KB of LDS per
   // workgroup instead of 70 KB -- three workgroups per CU, which is what this latency-bound kernel needs (12 wavefronts per CU)
   const uint32_t half = lane >> 5;
   uint32_t* trow = s_tr + ((wrow >> 1) + (lane & 31u)) * kTrRow;
-  for (uint32_t l0 = 0; l0 < L; l0 += 4) {
-    // Every request of the round goes out before anything is waited for, and the four entries' records are requested and
-    // consumed by ALL lanes (a lane without an entry reads the first record of the buffer and ignores it): a load that is issued
-    // on some paths only has an unknown place in the queue, the compiler then waits for EVERYTHING in front of the next write to
-    // its register -- the four entries of a round used to be four round trips one after the other.
-    lva_u32x4 ra4[4], rb4[4], qa[4], oa[4], ob[4]; lva_u32x2 qb[4]; uint32_t iu[4], ir[4]; bool on[4], chk[4];
+  // One round = four entries of every target of the wavefront.  NP = the plane count at pos (uniform; compile-time inside the
+  // instance).  At the two or three positions where pos - 1 has one plane less (`mixed`), an entry of a source list is read as if
+  // it had NP planes -- every lane the same straight-line loads -- and its top plane (the first words of the next record) is
+  // replaced by the zeros it stands for.
+  const bool mixed = nps != npd;
+  auto rounds = [&](auto npc) __attribute__((always_inline)) {
+    constexpr uint32_t NP = decltype(npc)::value;
+    constexpr uint32_t RW = 2u + 2u * NP;                 // words per record of the target's list
+    for (uint32_t l0 = 0; l0 < L; l0 += 4) {
+      // Every request of the round goes out before anything is waited for, and the four entries' records are requested and
+      // consumed by ALL lanes (a lane without an entry reads the first record of the buffer and ignores it): a load that is issued
+      // on some paths only has an unknown place in the queue, the compiler then waits for EVERYTHING in front of the next write to
+      // its register -- the four entries of a round used to be four round trips one after the other.
+      lva_u32x4_a8 ra4[4], qa[4]; lva_u32x2 rb2[4], rc2[4], qb[4], qc[4]; uint32_t iu[4], ir[4]; bool on[4], chk[4];
 #pragma unroll
-    for (uint32_t u = 0; u < 4; ++u) {
-      const uint32_t l = l0 + u;
-      on[u] = act && l < lc;
-      uint32_t i0 = 0;
-      const uint32_t f = locate((uint32_t)s_acc[l * NT] | ((uint32_t)(acc_hi >> l) & 1u) << 8, &i0);
-      iu[u] = on[u] ? i0 : 0u;
-      const uint32_t* rp = prev + (on[u] ? f : 0u);
-      ra4[u] = *LVA_GLOBAL(lva_u32x4, rp);                // score, fingerprint, words 4-5
-      rb4[u] = *LVA_GLOBAL(lva_u32x4, rp + 4);            // words 0-3
-    }
-#pragma unroll
-    for (uint32_t u = 0; u < 4; ++u) {                    // the match filed under an entry (one in ten): its loads travel with the others
-      const uint32_t l = l0 + u;
-      chk[u] = on[u] && ((rv0 >> l) & 1ull);
-      ir[u] = 0; qa[u] = lva_u32x4{0u, 0u, 0u, 0u}; qb[u] = lva_u32x2{0u, 0u};
-      if (chk[u]) {
-        const uint32_t fr = locate((uint32_t)s_rej0[l * NT] | ((uint32_t)(rh0 >> l) & 1u) << 8, &ir[u]);
-        qa[u] = *LVA_GLOBAL(lva_u32x4, prev + fr + 4);
-        qb[u] = *LVA_GLOBAL(lva_u32x2, prev + fr + 2);
-      }
-    }
-#pragma unroll
-    for (uint32_t u = 0; u < 4; ++u) {
-      uint32_t m[6] = {rb4[u].x, rb4[u].y, rb4[u].z, rb4[u].w, ra4[u].z, ra4[u].w};
-      const float sc = u2f(ra4[u].x) + ladd(iu[u]);
-      push_var<6>(m, iu[u] == 0 ? 0u : t.sh, iu[u] == 0 ? 0u : t.nb);
-      // (:799) the unused tail of the list: -inf, empty message
-      oa[u].x = on[u] ? f2u(sc) : kNegInfBits; oa[u].y = on[u] ? (iu[u] ? ra4[u].y ^ t.fpc : ra4[u].y) : 0u;
-      oa[u].z = on[u] ? m[4] : 0u; oa[u].w = on[u] ? m[5] : 0u;
-      ob[u].x = on[u] ? m[0] : 0u; ob[u].y = on[u] ? m[1] : 0u; ob[u].z = on[u] ? m[2] : 0u; ob[u].w = on[u] ? m[3] : 0u;
-      uint32_t q[6] = {qa[u].x, qa[u].y, qa[u].z, qa[u].w, qb[u].x, qb[u].y};
-      push_var<6>(q, ir[u] == 0 ? 0u : t.sh, ir[u] == 0 ? 0u : t.nb);
-      uint32_t diff = 0;
-#pragma unroll
-      for (int w = 0; w < 6; ++w) diff |= q[w] ^ m[w];
-      good &= !(chk[u] && diff != 0);
-    }
-    // whole lines out, half a wavefront's targets per round: instruction s stores the 128 bytes (4 records) of targets
-    // 32h + 8s .. 32h + 8s + 7, 16 bytes per thread
-#pragma unroll
-    for (uint32_t h2 = 0; h2 < 2; ++h2) {
-      if (half == h2) {
-#pragma unroll
-        for (uint32_t u = 0; u < 4; ++u) {
-          *reinterpret_cast<lva_u32x4*>(trow + 8 * u) = oa[u];
-          *reinterpret_cast<lva_u32x4*>(trow + 8 * u + 4) = ob[u];
+      for (uint32_t u = 0; u < 4; ++u) {
+        const uint32_t l = l0 + u;
+        on[u] = act && l < lc;
+        uint32_t i0 = 0;
+        const uint32_t f = locate((uint32_t)s_acc[l * NT] | ((uint32_t)(acc_hi >> l) & 1u) << 8, &i0);
+        iu[u] = on[u] ? i0 : 0u;
+        const uint32_t* rp = prev + (on[u] ? f : 0u);
+        ra4[u] = *LVA_GLOBAL(lva_u32x4_a8, rp);           // score, fingerprint, words 0-1
+        rb2[u] = lva_u32x2{0u, 0u}; rc2[u] = lva_u32x2{0u, 0u};
+        if constexpr (NP == 2) rb2[u] = *LVA_GLOBAL(lva_u32x2, rp + 4);       // words 2-3
+        if constexpr (NP == 3) {                                               // words 2-5: one load (32-byte records are 16-byte aligned)
+          const lva_u32x4_a8 v = *LVA_GLOBAL(lva_u32x4_a8, rp + 4);         // (8-byte aligned where pos - 1 has 24-byte records)
+          rb2[u] = lva_u32x2{v.x, v.y}; rc2[u] = lva_u32x2{v.z, v.w};
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      uint32_t tb[4]; lva_u32x4 tv[4];                    // (all eight LDS reads requested before the first store waits for one)
 #pragma unroll
-      for (uint32_t s8 = 0; s8 < 4; ++s8) {
-        const uint32_t Tl = 8 * s8 + (lane >> 3), piece = lane & 7u;       // target (local to the half), 16-byte piece of its line
-        tb[s8] = s_base[wrow + 32 * h2 + Tl];
-        tv[s8] = *reinterpret_cast<const lva_u32x4*>(s_tr + ((wrow >> 1) + Tl) * kTrRow + 4 * piece);
-      }
-#pragma unroll
-      for (uint32_t s8 = 0; s8 < 4; ++s8) {
-        if (tb[s8] != 0xFFFFFFFFu) {
-          uint32_t* dst = cur + tb[s8] + l0 * 8u + 4 * (lane & 7u);
-          __builtin_nontemporal_store(tv[s8].x, dst); __builtin_nontemporal_store(tv[s8].y, dst + 1);
-          __builtin_nontemporal_store(tv[s8].z, dst + 2); __builtin_nontemporal_store(tv[s8].w, dst + 3);
+      for (uint32_t u = 0; u < 4; ++u) {                  // the match filed under an entry (one in ten): its loads travel with the others
+        const uint32_t l = l0 + u;
+        chk[u] = on[u] && ((rv0 >> l) & 1ull);
+        ir[u] = 0; qa[u] = lva_u32x4_a8{0u, 0u, 0u, 0u}; qb[u] = lva_u32x2{0u, 0u}; qc[u] = lva_u32x2{0u, 0u};
+        if (chk[u]) {
+          const uint32_t fr = locate((uint32_t)s_rej0[l * NT] | ((uint32_t)(rh0 >> l) & 1u) << 8, &ir[u]);
+          qa[u] = *LVA_GLOBAL(lva_u32x4_a8, prev + fr);
+          if constexpr (NP == 2) qb[u] = *LVA_GLOBAL(lva_u32x2, prev + fr + 4);
+          if constexpr (NP == 3) {
+            const lva_u32x4_a8 v = *LVA_GLOBAL(lva_u32x4_a8, prev + fr + 4);
+            qb[u] = lva_u32x2{v.x, v.y}; qc[u] = lva_u32x2{v.z, v.w};
+          }
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      uint32_t ow[4][8];                                  // the four output records (2 + 2 np words each)
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u) {
+        uint32_t m[6] = {ra4[u].z, ra4[u].w, rb2[u].x, rb2[u].y, rc2[u].x, rc2[u].y};
+        if (mixed && iu[u] != 0) { m[2 * NP - 2] = 0; m[2 * NP - 1] = 0; }
+        const float sc = u2f(ra4[u].x) + ladd(iu[u]);
+        push_var<6>(m, iu[u] == 0 ? 0u : t.sh, iu[u] == 0 ? 0u : t.nb);
+        // (:799) the unused tail of the list: -inf, empty message
+        ow[u][0] = on[u] ? f2u(sc) : kNegInfBits; ow[u][1] = on[u] ? (iu[u] ? ra4[u].y ^ t.fpc : ra4[u].y) : 0u;
+#pragma unroll
+        for (int w = 0; w < 6; ++w) ow[u][2 + w] = on[u] ? m[w] : 0u;
+        uint32_t q[6] = {qa[u].z, qa[u].w, qb[u].x, qb[u].y, qc[u].x, qc[u].y};
+        if (mixed && ir[u] != 0) { q[2 * NP - 2] = 0; q[2 * NP - 1] = 0; }
+        push_var<6>(q, ir[u] == 0 ? 0u : t.sh, ir[u] == 0 ? 0u : t.nb);
+        uint32_t diff = 0;
+#pragma unroll
+        for (int w = 0; w < 6; ++w) diff |= q[w] ^ m[w];
+        good &= !(chk[u] && diff != 0);
+      }
+      // out in runs of 4 RW words per target, half a wavefront's targets per round: 32 targets x RW pieces of 16 bytes
+#pragma unroll
+      for (uint32_t h2 = 0; h2 < 2; ++h2) {
+        if (half == h2) {
+#pragma unroll
+          for (uint32_t u = 0; u < 4; ++u)
+#pragma unroll
+            for (uint32_t w = 0; w < 8; w += 2)
+              if (w < RW) *reinterpret_cast<lva_u32x2*>(trow + u * RW + w) = lva_u32x2{ow[u][w], ow[u][w + 1]};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t tb[4], td[4]; lva_u32x4 tv[4];           // (all LDS reads requested before the first store waits for one)
+#pragma unroll
+        for (uint32_t s8 = 0; s8 < 4; ++s8) {
+          if (s8 * 2 >= RW) break;                        // (32 targets x RW pieces: RW / 2 instructions)
+          const uint32_t p2 = 64 * s8 + lane;             // 16-byte piece p2 of the half's 32 RW pieces
+          const uint32_t Tl = NP == 1 ? p2 >> 2 : NP == 2 ? (p2 * 171u) >> 10 : p2 >> 3, piece = p2 - Tl * RW;
+          const bool in = p2 < 32u * RW;
+          tb[s8] = in ? s_base[wrow + 32 * h2 + (Tl & 31u)] : 0xFFFFFFFFu;
+          td[s8] = l0 * RW + 4 * piece;
+          tv[s8] = *reinterpret_cast<const lva_u32x4*>(s_tr + ((wrow >> 1) + (Tl & 31u)) * kTrRow + 4 * (in ? piece : 0u));
+        }
+#pragma unroll
+        for (uint32_t s8 = 0; s8 < 4; ++s8) {
+          if (s8 * 2 >= RW) break;
+          if (tb[s8] != 0xFFFFFFFFu) {
+            uint32_t* dst = cur + tb[s8] + td[s8];
+            __builtin_nontemporal_store(tv[s8].x, dst); __builtin_nontemporal_store(tv[s8].y, dst + 1);
+            __builtin_nontemporal_store(tv[s8].z, dst + 2); __builtin_nontemporal_store(tv[s8].w, dst + 3);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
     }
-  }
+  };
+  if (npd == 1) rounds(std::integral_constant<uint32_t, 1>{});
+  else if (npd == 2) rounds(std::integral_constant<uint32_t, 2>{});
+  else rounds(std::integral_constant<uint32_t, 3>{});
   if (!valid) return 0;
   if (why) return why;
   return good ? 0 : 4;
@@ -2283,7 +2326,7 @@ __global__ __launch_bounds__(8 * TSB) void lva_step_big_rec(StepArgs args, Geome
                                                           uint32_t* __restrict__ trellis, WorkHdr* __restrict__ hdr,
                                                           uint32_t* __restrict__ items) {
   __shared__ uint8_t s_acc[LL * 8 * TSB], s_rej0[LL * 8 * TSB];
-  __shared__ uint32_t s_tr[4 * TSB * kTrRow];        // 32 rows per wavefront
+  __shared__ __attribute__((aligned(16))) uint32_t s_tr[4 * TSB * kTrRow];        // 32 rows per wavefront
   __shared__ uint32_t s_base[8 * TSB];
   __shared__ float s_post[40];
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
@@ -2302,11 +2345,12 @@ __global__ __launch_bounds__(8 * TSB) void lva_step_big_rec(StepArgs args, Geome
   if (pos == 0) {                          // stay-only update of the 8 start states (:706-713)
     if (tile == cd.init / TSB && tid < 8) {
       const uint32_t k = tid, c = cd.init;
-      const uint32_t lst = (uint32_t)((uint64_t)k * g.sCrf), r0 = rec_sh(g, lst, c, 0);
+      const uint32_t np0 = cd.npair[0];
+      const uint32_t lst = (uint32_t)((uint64_t)k * g.sCrf), r0 = rec_sh(g, lst, c, 0, np0);
       const float s = u2f(prev[r0]) + ss.post_row[(k >= 4 ? 4u : k) * 8 + k];
       cur[r0] = f2u(s);
-      for (uint32_t w = 1; w < 8; ++w) cur[r0 + w] = prev[r0 + w];      // fingerprint and the (empty) message
-      for (uint32_t l = 1; l < g.L; ++l) cur[rec_sh(g, lst, c, l)] = kNegInfBits;
+      for (uint32_t w = 1; w < 2 + 2 * np0; ++w) cur[r0 + w] = prev[r0 + w];      // fingerprint and the (empty) message
+      for (uint32_t l = 1; l < g.L; ++l) cur[rec_sh(g, lst, c, l, np0)] = kNegInfBits;
     }
     return;
   }
@@ -2319,8 +2363,9 @@ __global__ __launch_bounds__(8 * TSB) void lva_step_big_rec(StepArgs args, Geome
   t.base = 0; t.reach = 0; t.pk1 = 0;
   const bool valid = tile_target<TSB>(cd, g, ss, pos, tile, tid, &t);
   // (wavefronts 0-1 hold the flip targets, 2-3 the flop targets: the merge width is uniform per wavefront)
-  const int why = tid < 4 * TSB ? big_merge_rec<LL, 8>(g, prev, cur, s_post, s_acc + tid, s_rej0 + tid, s_tr, s_base, valid, t, src)
-                                : big_merge_rec<LL, 2>(g, prev, cur, s_post, s_acc + tid, s_rej0 + tid, s_tr, s_base, valid, t, src);
+  const uint32_t pinfo = cd.rec[pos].info, npd = (pinfo >> 16) & 0xFFu, nps = pinfo >> 24;      // message planes in use at pos / at pos - 1
+  const int why = tid < 4 * TSB ? big_merge_rec<LL, 8>(g, prev, cur, s_post, s_acc + tid, s_rej0 + tid, s_tr, s_base, valid, t, src, npd, nps)
+                                : big_merge_rec<LL, 2>(g, prev, cur, s_post, s_acc + tid, s_rej0 + tid, s_tr, s_base, valid, t, src, npd, nps);
   if (why) {
     atomicAdd(&hdr->reason[why - 1], 1ull);
     const uint32_t idx = atomicAdd(&hdr->count[args.step_parity], 1u);
@@ -2364,8 +2409,9 @@ __global__ void lva_init_slot(Geometry g, const DevCode* __restrict__ codes, uin
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
     const uint32_t f = i % g.F, l = (i / g.F) % g.L, k = i / (g.F * g.L);
     const uint64_t blk = (uint64_t)k * g.sCrf + (uint64_t)l * g.sBlk;     // ring slot 0 = position 0
-    const uint64_t at = g.rec ? (f < 2 ? rec_sh(g, (uint32_t)((uint64_t)k * g.sCrf), cd.init, l) + f
-                                       : rec_word(g, (uint32_t)((uint64_t)k * g.sCrf), cd.init, l, f - 2, 3))
+    if (g.rec && f >= 2 + 2 * cd.npair[0]) continue;          // (record layout: only the words in use at position 0 exist)
+    const uint64_t at = g.rec ? (f < 2 ? rec_sh(g, (uint32_t)((uint64_t)k * g.sCrf), cd.init, l, cd.npair[0]) + f
+                                       : rec_word(g, (uint32_t)((uint64_t)k * g.sCrf), cd.init, l, f - 2, cd.npair[0]))
                               : blk + plane_off(g, f >> 1, cd.init) + (f & 1u);
     par0[at] = (f == 0 && l > 0) ? kNegInfBits : 0u;
   }
@@ -2438,7 +2484,7 @@ __global__ void lva_gather_final(Geometry g, const DevCode* __restrict__ codes, 
     uint32_t v = f == 0 ? kNegInfBits : 0u;
     if (((reach >> k) & 1u) && (f < 2 || ((f - 2) >> 1) < np)) {
       const uint32_t lst = (uint32_t)(((uint64_t)(pos % g.R) * 8 + (k >> compact_pos(cd, g, pos))) * g.sCrf);
-      v = f < 2 ? buf[rec_sh(g, lst, c, l) + f] : entry_word(g, buf, lst, c, l, f - 2, np);
+      v = f < 2 ? buf[rec_sh(g, lst, c, l, np) + f] : entry_word(g, buf, lst, c, l, f - 2, np);
     }
     out[i] = v;
   }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5: parity of the list kernel (three message planes, L >= 32) + its bench lines -> gpurun_out/r5big
 out=gpurun_out/r5big; mkdir -p $out
-timeout 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_chain.py tests/test_gpu_golden.py -m gpu -x -q -k "big_list or list64 or long_and_odd or L64 or L32 or L100" > $out/pytest.log 2>&1
+timeout 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_chain.py tests/test_gpu_golden.py -m gpu -x -q -k "big_list or list64 or long_and_odd or L64 or L32 or L100 or instances" > $out/pytest.log 2>&1
 tail -5 $out/pytest.log
 nb() { name=$1; shift; timeout 600 python3 bench.py "$@" --no-cpu-baseline > $out/${name}_bench.json 2> $out/nb_$name.err; python3 - $out/${name}_bench.json $name <<'PY'
 import json,sys
