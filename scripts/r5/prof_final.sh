@@ -36,3 +36,6 @@ nb m8L64 --mem-conv 8 --rate 3 --msg-len 164 --list-size 64 --slots 32 --steps 1
 nb m6 --mem-conv 6 --rate 1 --list-size 1 --steps 3 --warmup 1 --pool 4096
 nb m11L1 --list-size 1 --steps 2 --warmup 1 --pool 512
 for r in 1 2 5; do nb rate$r --mem-conv 11 --rate $r --steps 2 --warmup 1 --pool 128; done
+# the big-list kernel's counters on the same (final) library -> gpurun_out/r5pmc/r5_big64_pmc_summary.txt, r5_big64_bench_under_pmc.json
+bash scripts/r5/pmc.sh big64 "lva_step_big_rec" --list-size 64 --slots 8 --pool 8
+cp gpurun_out/r5pmc/r5_big64_pmc_summary.txt gpurun_out/r5pmc/r5_big64_bench_under_pmc.json $out/ 2>/dev/null
