@@ -297,10 +297,11 @@ int lva_decoder_create(const lva_config* cfg, lva_decoder** out) {
   // where the message has three planes and L is a multiple of 4 (Geometry::rec)
   const bool small = cfg->list_size == 1 || cfg->list_size == 2 || cfg->list_size == 4 || cfg->list_size == 8;
   const bool big = !lazy && !small && cfg->list_size <= 64 && (cfg->kernel == 0 || cfg->kernel == 2) && c.nconv >= 64;
-  // compact lists at one-bit positions (Geometry::cmp): the lazy kernels and the L = 1 kernel (lva_step_acs)
+  // compact lists at one-bit positions (Geometry::cmp): the lazy kernels, the L = 1 kernel (lva_step_acs) and the big-list kernel on
+  // the plane layout (make_geometry drops the flag where the record layout applies)
   const bool acs = cfg->list_size == 1 && (cfg->kernel == 0 || cfg->kernel == 2) && c.nconv >= 64;
   d->g = make_geometry(c.nconv, cfg->list_size, c.msg_bits(), (uint32_t)std::max<uint64_t>(ring, 1), lazy ? 1u : 0u, big ? 1u : 0u,
-                       acs ? 1u : 0u);
+                       (acs || big) ? 1u : 0u);
   if (d->g.sPar >= ((uint64_t)1 << 32)) { delete d; return LVA_ERR_TOO_MANY_STATES; }
 
   int ndev = 0;

@@ -116,7 +116,7 @@ struct Geometry {                // strides in 32-bit words
   uint32_t N, L, W, F, R, P;
   uint32_t sBlk;                 // one (ring, crf, list entry) block = N*F
   uint32_t lazy;                 // kernel mode 4: messages are materialised every second time step (lva_kernels.hip, "lazy")
-  uint32_t cmp;                  // compact lists (lazy mode, and the L = 1 kernel): at a one-bit position >= 1 a conv state has two COMPLEMENTARY bases
+  uint32_t cmp;                  // compact lists (every plane-layout fast kernel: lazy mode, the L = 1 kernel, the big-list kernel): at a one-bit position >= 1 a conv state has two COMPLEMENTARY bases
                                  // ({A,T} or {C,G}: its two predecessors differ in the register bit the step shifts out, which both generators tap), so 4 of its 8 crf lists exist -- the list of
                                  // crf state k is stored as list k >> 1 of the ring position (flip {A|C}, flip {T|G}, flop {A|C}, flop {T|G}).
                                  // Readers stage 4 x L rows of such a source position, all of them data, instead of 8 x L rows of which
@@ -133,7 +133,8 @@ inline Geometry make_geometry(uint32_t N, uint32_t L, uint32_t msg_bits, uint32_
   Geometry g;
   g.N = N; g.L = L; g.P = (msg_bits + 63) / 64; if (g.P == 0) g.P = 1;
   g.W = 2 * g.P; g.F = g.W + 2; g.R = R;
-  g.lazy = lazy; g.cmp = (lazy || cmp) ? 1u : 0u; g.rec = (rec && !lazy && g.P == 3 && L >= 32 && L % 4 == 0) ? 1u : 0u;   // (below 32 entries the plane layout is faster: measured)
+  g.lazy = lazy; g.rec = (rec && !lazy && g.P == 3 && L >= 32 && L % 4 == 0) ? 1u : 0u;   // (below 32 entries the plane layout is faster: measured)
+  g.cmp = ((lazy || cmp) && !g.rec) ? 1u : 0u;       // (the record layout keeps a list's entries together: a list that does not exist is a hole of whole lines)
   g.sBlk = N * g.F;
   // lazy mode: behind the L entry blocks of a (ring, crf) list, L back-pointer bytes per conv state ([conv][entry])
   g.sCrf = (uint64_t)g.sBlk * L + (lazy ? (uint64_t)N * L / 4 : 0); g.sRing = g.sCrf * 8;

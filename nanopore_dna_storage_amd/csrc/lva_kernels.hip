@@ -689,7 +689,7 @@ __device__ __forceinline__ void wave_target(const Geometry& g, const SlotStep& s
   for (uint32_t i = 0; i < 8; ++i) {
     cs[i] = NEG; cy[i] = 0;
     if (i < tg.nlists && ((tg.okmask >> i) & 1u) && lane < L) {
-      const uint32_t b = rec_sh(g, i == 0 ? tg.own : tg.src + list_crf(k, i) * sCrf, i == 0 ? tg.c : tg.cp, lane, i == 0 ? tg.np_dst : tg.np_src);
+      const uint32_t b = rec_sh(g, i == 0 ? tg.own : tg.src + (list_crf(k, i) >> tg.csrc) * sCrf, i == 0 ? tg.c : tg.cp, lane, i == 0 ? tg.np_dst : tg.np_src);
       const uint2 v = *reinterpret_cast<const uint2*>(prev + b);
       cs[i] = u2f(v.x); cy[i] = i != 0 ? v.y ^ tg.fpc : v.y;
     }
@@ -710,7 +710,7 @@ __device__ __forceinline__ void wave_target(const Geometry& g, const SlotStep& s
   if (lane < tg.nlists) addv = ss.post_row[tg.row * 8 + (lane == 0 ? k : list_crf(k, lane))];
   // word w of the candidate message built from entry (li, lj): per-lane arguments allowed
   auto word_of = [&](uint32_t li, uint32_t lj, uint32_t w) -> uint32_t {
-    const uint32_t lst = li == 0 ? tg.own : tg.src + list_crf(k, li) * sCrf;
+    const uint32_t lst = li == 0 ? tg.own : tg.src + (list_crf(k, li) >> tg.csrc) * sCrf;
     const uint32_t cv = li == 0 ? tg.c : tg.cp, np = li == 0 ? tg.np_dst : tg.np_src;
     const uint32_t v = entry_word(g, prev, lst, cv, lj, w, np);
     if (li == 0) return v;
@@ -786,7 +786,7 @@ __device__ __forceinline__ void wave_target(const Geometry& g, const SlotStep& s
     *reinterpret_cast<uint2*>(cur + rec_sh(g, tg.own, tg.c, lane, tg.np_dst)) = lane < l ? make_uint2(f2u(as), ay) : make_uint2(kNegInfBits, 0u);
     if (lane < l) {          // the whole message in the widest pieces the layout has (not word by word: every access of a lane is its own line)
       const uint32_t li = ax >> 16, lj = ax & 0xFFFFu;
-      const uint32_t lst = li == 0 ? tg.own : tg.src + list_crf(k, li) * sCrf, cv = li == 0 ? tg.c : tg.cp;
+      const uint32_t lst = li == 0 ? tg.own : tg.src + (list_crf(k, li) >> tg.csrc) * sCrf, cv = li == 0 ? tg.c : tg.cp;
       uint32_t m[8];
       if (g.rec) {           // record layout: the words in use at the entry's position follow its (score, fingerprint) pair
         const uint32_t npi = li == 0 ? tg.np_dst : tg.np_src;
@@ -1849,14 +1849,15 @@ constexpr uint32_t kBigInFlight = 6;   // output phase at L > 32: entries whose 
 template <int LL, int P, int NL>
 __device__ __forceinline__ int big_merge(const Geometry& g, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur,
                                           const float* s_post, uint8_t* s_acc, uint8_t* s_rej0, uint8_t* s_rej1,
-                                          const TileTarget& t, uint32_t src) {
+                                          const TileTarget& t, uint32_t src, uint32_t crow) {
   constexpr uint32_t NT = 8 * TSB;
   const float NEG = -INFINITY;
   const uint32_t L = g.L, N = g.N, sBlk = g.sBlk, sCrf = (uint32_t)g.sCrf, pw = 2 * g.N;
   const uint32_t k = t.k, row = k >= 4 ? 4u : k;
   const uint32_t own_c = t.own + 2 * t.c, src_c = src + 2 * t.cp;
   // word offset of the (score, fingerprint) pair of entry 0 of list i; its transition score
-  auto lbase = [&](uint32_t i) -> uint32_t { return i == 0 ? own_c : src_c + mul24(list_crf(k, i), sCrf); };
+  // (crow: the source position stores compact lists -- crf state kk's list is list kk >> 1 there, Geometry::cmp)
+  auto lbase = [&](uint32_t i) -> uint32_t { return i == 0 ? own_c : src_c + mul24(list_crf(k, i) >> crow, sCrf); };
   auto ladd = [&](uint32_t i) -> float { return s_post[row * 8 + (i == 0 ? k : list_crf(k, i))]; };
   int why = 0;
 
@@ -1948,7 +1949,7 @@ __device__ __forceinline__ int big_merge(const Geometry& g, const uint32_t* __re
   auto locate = [&](uint32_t from9, uint32_t* i_out) -> uint32_t {
     const uint32_t i = from9 >> 6, j = from9 & 63u;
     *i_out = i;
-    return (i == 0 ? t.own : src + mul24(list_crf(k, i), sCrf)) + mul24(j, sBlk);
+    return (i == 0 ? t.own : src + mul24(list_crf(k, i) >> crow, sCrf)) + mul24(j, sBlk);
   };
   // outputs, entry l of the whole wavefront at a time (:771-774, :780-783, :799).  Every fingerprint
   // match filed under an entry must be the same message (else: collision, the exact path decides).
@@ -2042,8 +2043,9 @@ __global__ __launch_bounds__(8 * TSB) void lva_step_big(StepArgs args, Geometry 
   const uint32_t src = (uint32_t)((uint64_t)((pos - 1) % g.R) * 8 * g.sCrf);
   TileTarget t;
   if (!tile_target<TSB>(cd, g, ss, pos, tile, tid, &t)) return;
-  const int why = t.k < 4 ? big_merge<LL, P, 8>(g, prev, cur, s_post, s_acc + tid, s_rej0 + tid, s_rej1 + tid, t, src)
-                          : big_merge<LL, P, 2>(g, prev, cur, s_post, s_acc + tid, s_rej0 + tid, s_rej1 + tid, t, src);
+  const uint32_t crow = source_compact(g, cd, ss, blockIdx.y, pos);
+  const int why = t.k < 4 ? big_merge<LL, P, 8>(g, prev, cur, s_post, s_acc + tid, s_rej0 + tid, s_rej1 + tid, t, src, crow)
+                          : big_merge<LL, P, 2>(g, prev, cur, s_post, s_acc + tid, s_rej0 + tid, s_rej1 + tid, t, src, crow);
   if (why) {
     atomicAdd(&hdr->reason[why - 1], 1ull);
     const uint32_t idx = atomicAdd(&hdr->count[args.step_parity], 1u);
