@@ -37,6 +37,48 @@ __global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ bu
   out[gid] = acc;
 }
 
+
+// Streaming counterparts (what a request costs when the lanes of an instruction ask for neighbouring bytes): 16 bytes per lane,
+// RUN bytes contiguous per group of RUN/16 lanes, the groups' runs at pseudo-random RUN-aligned places of the footprint
+// (RUN = 1024: the whole instruction contiguous; 128 / 64: the big-list kernel's output runs).  WRITE: non-temporal stores.
+template <int RUN, bool WRITE>
+__global__ __launch_bounds__(256) void k_runs(uint32_t* __restrict__ buf, uint32_t runs_mask, int iters, uint32_t* __restrict__ out) {
+  constexpr uint32_t LPR = RUN / 16;                       // lanes per run
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  uint32_t acc = 0;
+  for (int i = 0; i < iters; ++i) {
+    uint32_t x = (wave * 1315423911u) ^ ((uint32_t)i * 2654435761u) ^ ((lane / LPR) * 40503u);
+    x = x * 1664525u + 1013904223u;
+    const uint32_t run = (x >> 5) & runs_mask;
+    uint32_t* p = buf + (size_t)run * (RUN / 4) + (lane % LPR) * 4u;
+    if (WRITE) {
+      __builtin_nontemporal_store(x, p); __builtin_nontemporal_store(x + 1, p + 1);
+      __builtin_nontemporal_store(x + 2, p + 2); __builtin_nontemporal_store(x + 3, p + 3);
+    } else {
+      const uint4 q = *reinterpret_cast<const uint4*>(p);
+      acc += q.x ^ q.y ^ q.z ^ q.w;
+    }
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+template <int RUN, bool WRITE>
+static void time_runs(const char* foot, size_t bytes, uint32_t* buf, uint32_t* out, hipEvent_t e0, hipEvent_t e1) {
+  const uint32_t mask = (uint32_t)(bytes / RUN - 1);
+  const int nblk = 256 * 3, iters = 600;
+  hipLaunchKernelGGL((k_runs<RUN, WRITE>), dim3(nblk), dim3(256), 0, 0, buf, mask, 8, out);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL((k_runs<RUN, WRITE>), dim3(nblk), dim3(256), 0, 0, buf, mask, iters, out);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+  const double instr = (double)nblk * 4 * iters, by = instr * 1024.0;
+  printf("%-10s %-6s run %-5d | %8.1f ns per wave-instr per CU  %8.3g runs/s  %6.2f TB/s\n", foot, WRITE ? "store" : "load", RUN,
+         ms * 1e6 / (instr / 256), instr * (1024 / RUN) / (ms * 1e-3), by / (ms * 1e-3) * 1e-12);
+}
+
 int main() {
   const size_t maxbytes = (size_t)4 << 30;
   uint32_t* buf; uint32_t* out;
@@ -75,6 +117,15 @@ int main() {
               const double lines = (double)nblk * 4 * lanes * iters * infl / (ms * 1e-3);
               printf("%-10s %-6d %-6d %-5d %-6d %-4d | %12.1f %14.1f %12.3g\n", f.name, bytes, lanes, infl, wgs * 4, dep, ns, ns * clk_khz * 1e-6, lines);
             }
+  }
+  printf("\nneighbouring lanes (16 bytes per lane; runs at random RUN-aligned places; 12 wavefronts per CU)\n");
+  for (const Foot& f : foots) {
+    time_runs<1024, false>(f.name, f.bytes, buf, out, e0, e1);
+    time_runs<128, false>(f.name, f.bytes, buf, out, e0, e1);
+    time_runs<64, false>(f.name, f.bytes, buf, out, e0, e1);
+    time_runs<1024, true>(f.name, f.bytes, buf, out, e0, e1);
+    time_runs<128, true>(f.name, f.bytes, buf, out, e0, e1);
+    time_runs<64, true>(f.name, f.bytes, buf, out, e0, e1);
   }
   return 0;
 }
