@@ -25,7 +25,7 @@ tr m14 --mem-conv 14 --rate 7 --slots 8 --steps 2 --warmup 1 --pool 32
 tr big64 --list-size 64 --slots 8 --steps 1 --warmup 1 --pool 16
 tr m8 --mem-conv 8 --rate 3 --msg-len 164 --steps 3 --warmup 1 --pool 1024
 tr m8L64 --mem-conv 8 --rate 3 --msg-len 164 --list-size 64 --slots 32 --steps 1 --warmup 1 --pool 64
-tr m6 --mem-conv 6 --rate 1 --list-size 1 --steps 3 --warmup 1 --pool 4096
+tr m6 --mem-conv 6 --rate 1 --list-size 1 --steps 3 --warmup 1 --pool 8192
 tr m11L1 --list-size 1 --steps 2 --warmup 1 --pool 512
 # the same configurations without the profiler, and the rate table of DESIGN_HISTORY 4e (one-bit steps: all / half / a third)
 nb() { name=$1; shift; python3 bench.py "$@" --no-cpu-baseline --no-cross-check > $out/r5_${name}_bench.json 2> $out/nb_$name.err; cut -c1-120 $out/r5_${name}_bench.json; }
@@ -33,7 +33,7 @@ nb m14 --mem-conv 14 --rate 7 --slots 8 --steps 2 --warmup 1 --pool 32
 nb L64 --list-size 64 --slots 8 --steps 1 --warmup 1 --pool 16
 nb m8 --mem-conv 8 --rate 3 --msg-len 164 --steps 3 --warmup 1 --pool 1024
 nb m8L64 --mem-conv 8 --rate 3 --msg-len 164 --list-size 64 --slots 32 --steps 1 --warmup 1 --pool 64
-nb m6 --mem-conv 6 --rate 1 --list-size 1 --steps 3 --warmup 1 --pool 4096
+nb m6 --mem-conv 6 --rate 1 --list-size 1 --steps 3 --warmup 1 --pool 8192
 nb m11L1 --list-size 1 --steps 2 --warmup 1 --pool 512
 for r in 1 2 5; do nb rate$r --mem-conv 11 --rate $r --steps 2 --warmup 1 --pool 128; done
 # the big-list kernel's counters on the same (final) library -> gpurun_out/r5pmc/r5_big64_pmc_summary.txt, r5_big64_bench_under_pmc.json

@@ -248,7 +248,23 @@ def test_hundreds_of_slots(oracle, L):
         assert np.array_equal(g[0], wm) and np.array_equal(g[1].view(np.uint32), ws.view(np.uint32))
 
 
+def test_list_size_one_through_its_default_slots(oracle):
+    """L = 1 takes four times the slots of the list kernels (4096 at m = 6): 4200 reads of different lengths through them in one
+    call -- every slot index in use, the first 104 slots refilled -- against the CPU oracle."""
+    reads = [synth.make_read(6, 1, 24, 12000 + i, rc=bool(i % 3 == 0), margin=2.5 + (i % 4), quantum=0.5 if i % 7 == 0 else None)
+             for i in range(4200)]
+    with pkg.Decoder(6, 1, 24, list_size=1, max_deviation=6) as dec:
+        assert dec.profile()["slots"] == 4096
+        got = dec.decode([x["post"] for x in reads], rc=[x["rc"] for x in reads])
+    codes = {rc: oracle.OracleCode(6, 1, 24, rc=rc) for rc in (False, True)}
+    for i, (x, g) in enumerate(zip(reads, got)):
+        wm, ws = codes[x["rc"]].decode(x["post"], 1, 6)
+        assert not isinstance(g, int), "read %d: error %r" % (i, g)
+        assert np.array_equal(g[0], wm) and np.array_equal(g[1].view(np.uint32), ws.view(np.uint32)), "read %d" % i
+
+
 def test_default_slot_count_grows_for_small_trellises():
-    for m, r, ml, want in ((6, 1, 60, 1024), (8, 1, 100, 256), (11, 1, 40, 64)):
-        with pkg.Decoder(m, r, ml, list_size=2, max_deviation=20) as dec:
+    for m, r, ml, L, want in ((6, 1, 60, 2, 1024), (8, 1, 100, 2, 256), (11, 1, 40, 2, 64),
+                              (6, 1, 60, 1, 4096), (8, 1, 100, 1, 1024), (11, 1, 40, 1, 128)):     # L = 1: launches a quarter as long
+        with pkg.Decoder(m, r, ml, list_size=L, max_deviation=20) as dec:
             assert dec.profile()["slots"] == want
