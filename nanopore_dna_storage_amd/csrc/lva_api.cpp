@@ -519,9 +519,24 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
     *out = d->ev_pool[ev_used++];
     return LVA_OK;
   };
+  InitBatch ib; GatherBatch gb;
+  ib.n = 0; ib.pad = 0; gb.n = 0;
+  auto flush_inits = [&]() -> int {
+    const int e = launch_init_slots(g, d->d_codes, d->d_trellis, ib, d->d_slots, d->stream);
+    ib.n = 0;
+    if (e) { g_hip_error = hipGetErrorString((hipError_t)e); return LVA_ERR_HIP; }
+    return LVA_OK;
+  };
+  auto flush_gathers = [&]() -> int {
+    const int e = launch_gather_finals(g, d->d_codes, d->d_trellis, gb, d->d_results, d->stream);
+    gb.n = 0;
+    if (e) { g_hip_error = hipGetErrorString((hipError_t)e); return LVA_ERR_HIP; }
+    return LVA_OK;
+  };
   for (;;) {
     size_t waiting = 0;              // slots whose read starts with the next launch (lazy mode's phase alignment)
-    // (re)fill idle slots: the read's descriptor and initial scores (:657-663) go in stream order
+    // (re)fill idle slots: the reads' descriptors and initial scores (:657-663) go in stream order, a batch of slots per launch
+    // (behind the gathers of the reads that left them: the retire loop below runs first)
     for (size_t s = 0; s < slot.size(); ++s) {
       if (slot[s].read >= 0 || next >= order.size()) continue;
       const int32_t r = order[next++];
@@ -535,12 +550,13 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
       sd.start = d->launch_no + (d->kernel == 4 ? (d->launch_no & 1u) : 0u); sd.pad = 0;
       slot[s].read = r; slot[s].end = sd.start + sd.nblk;
       if (sd.start != d->launch_no) ++waiting;
-      const int e = launch_init_slot(g, d->d_codes, d->d_trellis, (uint32_t)s, sd, d->d_slots, d->stream);
-      if (e) { g_hip_error = hipGetErrorString((hipError_t)e); return LVA_ERR_HIP; }
+      ib.slot[ib.n] = (uint32_t)s; ib.desc[ib.n] = sd;
+      if (++ib.n == (uint32_t)kTurnoverBatch) { const int st = flush_inits(); if (st) return st; }
       d->prof.algorithmic_bytes += d->code[sd.orient].algorithmic_bytes(sd.nblk, L, d->max_dev);
       d->prof.working_bytes += d->code[sd.orient].working_bytes(sd.nblk, L, d->max_dev);
       ++active;
     }
+    { const int st = flush_inits(); if (st) return st; }
     if (active == 0) break;
     StepArgs a;
     a.slots = d->d_slots; a.steps = d->d_steps; a.nslots = (uint32_t)slot.size(); a.band_max = band_max;
@@ -582,14 +598,14 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
       const uint32_t nb = (uint32_t)len[r], orient = rc_flags && rc_flags[r] ? 1u : 0u;
       const uint32_t last = band[band_at[(size_t)r] + nb - 1];
       if ((last & 0xFFFFu) <= npos - 1 && npos - 1 < ((last >> 16) & 0x3FFFu)) {   // otherwise the final state was never written: empty list
-        GatherArgs ga{(uint32_t)s, (uint32_t)(nb & 1u), orient, (uint32_t)r, nb};
-        const int e = launch_gather_final(g, d->d_codes, d->d_trellis, ga, d->d_results, d->stream);
-        if (e) { g_hip_error = hipGetErrorString((hipError_t)e); return LVA_ERR_HIP; }
+        gb.a[gb.n] = GatherArgs{(uint32_t)s, (uint32_t)(nb & 1u), orient, (uint32_t)r, nb};
+        if (++gb.n == (uint32_t)kTurnoverBatch) { const int st = flush_gathers(); if (st) return st; }
         gathered[(size_t)r] = 1;
       }
       slot[s].read = -1;
       --active;
     }
+    { const int st = flush_gathers(); if (st) return st; }
   }
   if (!first_step) HIP_TRY(hipEventRecord(d->ev_step1, d->stream));
   host.assign((size_t)n * rec_words, 0u);

@@ -160,4 +160,17 @@ struct GatherArgs {
   uint32_t nblk;                 // blocks of the read (lazy mode: whether the last step stored messages or back-pointers)
 };
 
+// Reads enter and leave their slots in batches: one launch serves every slot that turns over at this step (small trellises turn
+// several over per step, and a launch per slot -- two per read -- was 8 % of the device time at m = 6, L = 1), one workgroup each.
+constexpr int kTurnoverBatch = 16;
+struct InitBatch {
+  uint32_t n, pad;
+  uint32_t slot[kTurnoverBatch];
+  SlotDesc desc[kTurnoverBatch];
+};
+struct GatherBatch {
+  uint32_t n;
+  GatherArgs a[kTurnoverBatch];
+};
+
 }  // namespace lva

@@ -16,10 +16,10 @@ int launch_step_wave(const StepArgs& a, const Geometry& g, const DevCode* codes,
 bool wave_kernel_available(const Geometry& g);
 // this launch's SlotStep records (a.steps), to be enqueued right before the step launch
 int launch_prepare_step(const StepArgs& a, const DevCode* codes, SlotStep* steps, void* stream);
-// initial scores of a slot + its descriptor (the read enters the slot)
-int launch_init_slot(const Geometry& g, const DevCode* codes, uint32_t* trellis, uint32_t slot, const SlotDesc& desc,
-                     SlotDesc* slots, void* stream);
-int launch_gather_final(const Geometry& g, const DevCode* codes, const uint32_t* trellis, const GatherArgs& a,
-                        uint32_t* results, void* stream);
+// initial scores of up to kTurnoverBatch slots + their descriptors (the reads enter their slots); no launch for an empty batch
+int launch_init_slots(const Geometry& g, const DevCode* codes, uint32_t* trellis, const InitBatch& batch, SlotDesc* slots, void* stream);
+// the final lists of up to kTurnoverBatch finished reads -> their result records
+int launch_gather_finals(const Geometry& g, const DevCode* codes, const uint32_t* trellis, const GatherBatch& batch,
+                         uint32_t* results, void* stream);
 
 }  // namespace lva

@@ -2402,7 +2402,10 @@ __global__ void lva_prepare_step(StepArgs a, const DevCode* __restrict__ codes, 
 
 // (:657-663) score 0 at (pos 0, initial conv state, every crf state, list entry 0), empty message
 __global__ void lva_init_slot(Geometry g, const DevCode* __restrict__ codes, uint32_t* __restrict__ trellis,
-                              uint32_t slot, SlotDesc desc, SlotDesc* __restrict__ slots) {
+                              InitBatch batch, SlotDesc* __restrict__ slots) {
+  if (blockIdx.x >= batch.n) return;
+  const uint32_t slot = batch.slot[blockIdx.x];
+  const SlotDesc desc = batch.desc[blockIdx.x];
   const uint32_t orient = desc.orient;
   if (threadIdx.x == 0) slots[slot] = desc;             // the read enters the slot: later step launches see it
   const DevCode& cd = codes[orient];
@@ -2423,7 +2426,9 @@ __global__ void lva_init_slot(Geometry g, const DevCode* __restrict__ codes, uin
 // [crf][l][score, fingerprint, message words], writing -inf scores for crf states that are
 // not stored (:806-815 reads them as -inf)
 __global__ void lva_gather_final(Geometry g, const DevCode* __restrict__ codes, const uint32_t* __restrict__ trellis,
-                                 GatherArgs a, uint32_t* __restrict__ results) {
+                                 GatherBatch batch, uint32_t* __restrict__ results) {
+  if (blockIdx.x >= batch.n) return;
+  const GatherArgs a = batch.a[blockIdx.x];
   const DevCode& cd = codes[a.orient];
   const uint32_t pos = cd.npos - 1, c = cd.fin;
   const uint32_t* buf = trellis + (uint64_t)a.slot * g.sSlot + (uint64_t)a.parity * g.sPar;
@@ -2627,15 +2632,16 @@ int launch_prepare_step(const StepArgs& a, const DevCode* codes, SlotStep* steps
   return (int)hipGetLastError();
 }
 
-int launch_init_slot(const Geometry& g, const DevCode* codes, uint32_t* trellis, uint32_t slot, const SlotDesc& desc,
-                     SlotDesc* slots, void* stream) {
-  hipLaunchKernelGGL(lva_init_slot, dim3(1), dim3(64), 0, (hipStream_t)stream, g, codes, trellis, slot, desc, slots);
+int launch_init_slots(const Geometry& g, const DevCode* codes, uint32_t* trellis, const InitBatch& batch, SlotDesc* slots, void* stream) {
+  if (batch.n == 0) return 0;
+  hipLaunchKernelGGL(lva_init_slot, dim3(batch.n), dim3(64), 0, (hipStream_t)stream, g, codes, trellis, batch, slots);
   return (int)hipGetLastError();
 }
 
-int launch_gather_final(const Geometry& g, const DevCode* codes, const uint32_t* trellis, const GatherArgs& a,
-                        uint32_t* results, void* stream) {
-  hipLaunchKernelGGL(lva_gather_final, dim3(1), dim3(64), 0, (hipStream_t)stream, g, codes, trellis, a, results);
+int launch_gather_finals(const Geometry& g, const DevCode* codes, const uint32_t* trellis, const GatherBatch& batch,
+                         uint32_t* results, void* stream) {
+  if (batch.n == 0) return 0;
+  hipLaunchKernelGGL(lva_gather_final, dim3(batch.n), dim3(64), 0, (hipStream_t)stream, g, codes, trellis, batch, results);
   return (int)hipGetLastError();
 }
 
