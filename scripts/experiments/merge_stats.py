@@ -92,3 +92,6 @@ tw = arr("lva_stats_tw", 3); notw = arr("lva_stats_pops_notw", 8 * 65 + 1)
 print("with one twin word per entry + one forward map per list and step (what a GPU lane would have): %.2f%% of the duplicate pops named, "
       "%d named wrongly (must be 0)" % (100 * tw[0] / tw[2], tw[1]))
 print("without those pops: mean pops %.2f, expected maximum over 64 targets %.2f" % ((notw * np.arange(len(notw))).sum() / notw.sum(), wave_max(notw)))
+ti = arr("lva_stats_ties", 4)
+print("targets with a tie (equal score still in the heap at a pop): %.3g = %.2f%% of the targets; every tie between two copies of ONE message in %.1f%% of them "
+      "(tie events %.3g, benign %.1f%%)" % (ti[0], 100 * ti[0] / T, 100 * ti[1] / max(ti[0], 1), ti[2], 100 * ti[3] / max(ti[2], 1)))

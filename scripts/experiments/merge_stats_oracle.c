@@ -452,7 +452,12 @@ uint64_t lva_stats_pops_nolin[8 * ST_MAXL + 1];     /* pops per target if same-p
  * forward map per list and step (old index -> new index), a step stamp per list (stale rows at the band edge give no twins) */
 uint64_t lva_stats_tw[3];                           /* [0] duplicate pops named by the twin words, [1] named although not a duplicate (must be 0), [2] all duplicate pops */
 uint64_t lva_stats_pops_notw[8 * ST_MAXL + 1];      /* pops per target without the duplicate pops the twin words name */
+/* ties: targets in which a popped candidate had an equal score still in the heap (the GPU's fast paths leave such a target to the exact
+ * path): [0] targets with a tie, [1] of them: every tie was between exactly two candidates carrying the SAME message (whichever pops
+ * first, the list comes out the same), [2] tie events, [3] benign tie events */
+uint64_t lva_stats_ties[4];
 void lva_oracle_stats_reset(void) {
+  memset(lva_stats_ties, 0, sizeof lva_stats_ties);
   memset(lva_stats_dup_kind, 0, sizeof lva_stats_dup_kind); memset(lva_stats_pops_noss, 0, sizeof lva_stats_pops_noss);
   memset(lva_stats_dup_lineage, 0, sizeof lva_stats_dup_lineage); memset(lva_stats_pops_nolin, 0, sizeof lva_stats_pops_nolin);
   memset(lva_stats_tw, 0, sizeof lva_stats_tw); memset(lva_stats_pops_notw, 0, sizeof lva_stats_pops_notw);
@@ -604,6 +609,7 @@ int lva_oracle_decode(const lva_oracle_code *c, const float *post, uint32_t nblk
           heap_build(heap, hn);
           uint32_t l = 0;
 #ifdef LVA_ORACLE_STATS
+          uint32_t st_tie_events = 0, st_tie_benign = 0;
           uint32_t st_depth[MAX_PRED] = {0}, st_pops = 0, st_dupk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_acc_ps[ST_MAXL]; const int st_heads = hn;
           /* twin words of the own list, translated through the forward maps of the (fresh) source lists */
           uint16_t tw_now[ST_MAXL], tw_new[ST_MAXL]; uint8_t tw_fnew[ST_MAXL], tw_dead_stay[ST_MAXL], tw_dead_src[MAX_PRED][ST_MAXL];
@@ -629,6 +635,18 @@ int lva_oracle_decode(const lva_oracle_code *c, const float *post, uint32_t nblk
             const pred_t *pi = &pl[top.ps];
             const size_t from = from_of[top.ps];
             msg_push(cand, prev->msg + (from * L + top.j) * W, W, pi->shift, pi->newbits);
+#ifdef LVA_ORACLE_STATS
+            {
+              int neq = 0, same = 0;
+              for (int e = 0; e < hn; e++)
+                if (heap[e].score == top.score) {
+                  uint32_t other[8];
+                  msg_push(other, prev->msg + (from_of[heap[e].ps] * L + heap[e].j) * W, W, pl[heap[e].ps].shift, pl[heap[e].ps].newbits);
+                  neq++; same += memcmp(other, cand, W * sizeof(uint32_t)) == 0;
+                }
+              if (neq) { st_tie_events++; if (neq == 1 && same == 1) st_tie_benign++; }
+            }
+#endif
             int dup = 0;
             for (uint32_t a = 0; a < l && !dup; a++) {
               dup = (memcmp(cm + a * W, cand, W * sizeof(uint32_t)) == 0);
@@ -684,6 +702,10 @@ int lva_oracle_decode(const lva_oracle_code *c, const float *post, uint32_t nblk
           }
 #ifdef LVA_ORACLE_STATS
           if (st_heads > 0) lva_oracle_stats_record(L, np, st_depth, st_pops, l, st_dupk);
+          if (st_tie_events) {
+#pragma omp critical(lva_stats_ties)
+            { lva_stats_ties[0]++; lva_stats_ties[1] += st_tie_events == st_tie_benign; lva_stats_ties[2] += st_tie_events; lva_stats_ties[3] += st_tie_benign; }
+          }
           if (L < ST_MAXL) {
             for (uint32_t j = 0; j < L; j++) { tw_w[st_cb][st * L + j] = j < l ? tw_new[j] : 0; tw_f[st_cb][st * L + j] = tw_fnew[j]; }
             tw_stamp[st_cb][st] = t + 1;
