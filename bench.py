@@ -106,7 +106,7 @@ class StubDecoder:
     8-rank argument / shard / gather / JSON path of this script runs in a container without GPUs.  Never measures anything."""
 
     def __init__(self, list_size, msg_len, slots):
-        self.L, self.ml, self.slots, self.p = list_size, msg_len, slots or 64, None
+        self.L, self.ml, self.slots, self.p = list_size, msg_len, slots or 128, None
 
     def profile(self):
         return self.p or dict(slots=self.slots, kernel=1)

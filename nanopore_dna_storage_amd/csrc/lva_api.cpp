@@ -325,7 +325,7 @@ int lva_decoder_create(const lva_config* cfg, lva_decoder** out) {
   uint64_t budget = cfg->mem_budget_bytes ? cfg->mem_budget_bytes : (uint64_t)(free_b * 0.6);
   // reads in flight: enough of them that one trellis-step launch fills the chip -- a launch has
   // (2^m / 64 tiles) x (<= 2 max_deviation positions) x slots workgroups, so small trellises take
-  // proportionally more slots (64 at m >= 11, 256 at m = 8, 1024 at m = 6: measured), and four times as many at
+  // proportionally more slots (128 at m >= 11, 256 at m = 8, 1024 at m = 6: measured), and four times as many at
   // L = 1, whose launches are that much shorter (m = 6: 0.11 ms at 1024 slots; 4096 slots +15 %, m = 11: 128 slots +5 %: round 5,
   // scripts/r5/slot_sweep_small.sh); bounded by the memory budget and by the work-list item format (21 - m bits of slot index)
   const uint64_t hard = std::min<uint64_t>(kMaxSlotsLimit, 1ull << (21 - std::min(c.mem_conv, 20)));
@@ -333,7 +333,8 @@ int lva_decoder_create(const lva_config* cfg, lva_decoder** out) {
   if (cfg->max_slots > 0) slots = std::min(slots, (int)cfg->max_slots);
   else {
     const uint64_t per_l = cfg->list_size == 1 ? 4 : 1;
-    slots = std::min<int>(slots, (int)std::max<uint64_t>(64, std::min<uint64_t>(1024 * per_l, per_l * 32ull * 2048 / c.nconv)));
+    // (never fewer than 128: the tail of a launch -- 74 k workgroups over 1024 resident ones at 64 slots of m = 11 -- costs 1.8 %)
+    slots = std::min<int>(slots, (int)std::max<uint64_t>(128, std::min<uint64_t>(1024 * per_l, per_l * 32ull * 2048 / c.nconv)));
   }
   if (slots < 1) return fail(LVA_ERR_NOMEM);
   d->slots = slots;

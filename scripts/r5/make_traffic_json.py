@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/r5_traffic.json from the counter CSVs of scripts/r5/prof_final.sh (gpurun_out/r5prof/{fetch,write,sq1,sq2,ta}) and
-the bench line of the same run: HBM bytes per launch of the dominant kernel at the DEFAULT 64 slots, and what the SQ / TA
+the bench line of the same run: HBM bytes per launch of the dominant kernel at the DEFAULT 128 slots, and what the SQ / TA
 counters say holds it back (bench.py copies `limiter` into its roofline object).
 
 Since round 4 the slots are phase-aligned -- a launch runs ONE instance of lva_step_lazy (anchor on even launches, odd-step on odd
@@ -27,7 +27,7 @@ def counters(name):
 
 
 (fetch, nf), (write, _), (sq1, _), (sq2, _), (ta, _) = (counters(n) for n in ("fetch", "write", "sq1", "sq2", "ta"))
-bench = json.loads([ln for ln in open(src + "/r5_lazy64_bench_under_pmc.json") if ln.startswith("{")][-1])
+bench = json.loads([ln for ln in open(src + "/r5_lazy128_bench_under_pmc.json") if ln.startswith("{")][-1])
 kern, calls = {}, {}
 for k in fetch.index:
     cyc = ta.loc[k, "GRBM_GUI_ACTIVE"] / 8.0                     # summed over the 8 XCDs
@@ -53,8 +53,8 @@ out = {
     # the library these counters were taken on (lva_version()'s source hash, written into the bench line): bench.py fills its
     # `traffic` field from this file only when it runs the same build
     "build_id": bench["library"]["build_id"], "library": bench["library"]["version"],
-    "_comment": "HBM traffic and limiter of the dominant kernel on the benchmark shape at the DEFAULT 64 read slots: rocprofv3 --pmc passes "
-                "(FETCH_SIZE and WRITE_SIZE separately; SQ and TA sets) over `python3 bench.py --steps 1 --warmup 0 --reads-per-step 64 --pool 64 "
+    "_comment": "HBM traffic and limiter of the dominant kernel on the benchmark shape at the DEFAULT 128 read slots: rocprofv3 --pmc passes "
+                "(FETCH_SIZE and WRITE_SIZE separately; SQ and TA sets) over `python3 bench.py --steps 1 --warmup 0 --reads-per-step 128 --pool 128 "
                 "--no-cpu-baseline --no-launch-events --no-cross-check`, restricted to the lva_step_lazy kernels (--kernel-include-regex) so that the "
                 "passes return in seconds.  A launch runs one instance (anchor / odd step) over all slots: per-launch figures are the mean over "
                 "the instances' launches.  FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (scattered 8/16-byte gathers are "

@@ -10,15 +10,15 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -
 cat $out/trace/*/*kernel_stats.csv > $out/r5_default_kernel_stats.csv 2>/dev/null
 grep '^{' $out/trace.log | tail -1 > $out/r5_default_bench_under_trace.json
 rm -rf $out/trace
-B="python3 bench.py --steps 1 --warmup 0 --reads-per-step 64 --pool 64 --no-cpu-baseline --no-launch-events --no-cross-check"
+B="python3 bench.py --steps 1 --warmup 0 --reads-per-step 128 --pool 128 --no-cpu-baseline --no-launch-events --no-cross-check"
 run() { name=$1; shift; s=$(date +%s); timeout 600 rocprofv3 --kernel-include-regex "lva_step_lazy" "$@" --output-format csv -d $out/$name -- $B > $out/$name.log 2>&1; echo "$name rc=$? $(( $(date +%s)-s )) s"; }
 run fetch --pmc FETCH_SIZE
 run write --pmc WRITE_SIZE
 run sq1 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 run sq2 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
 run ta --pmc TA_TA_BUSY_sum GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum
-python3 scripts/pmc_summary.py $out/fetch $out/write $out/sq1 $out/sq2 $out/ta > $out/r5_lazy64_pmc_summary.txt 2>&1
-grep '^{' $out/fetch.log | tail -1 > $out/r5_lazy64_bench_under_pmc.json
+python3 scripts/pmc_summary.py $out/fetch $out/write $out/sq1 $out/sq2 $out/ta > $out/r5_lazy128_pmc_summary.txt 2>&1
+grep '^{' $out/fetch.log | tail -1 > $out/r5_lazy128_bench_under_pmc.json
 python3 scripts/r5/make_traffic_json.py $out $out/r5_traffic.json
 tr() { name=$1; shift; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/t_$name -- python3 bench.py "$@" --no-cpu-baseline --no-cross-check > $out/t_$name.log 2>&1; cat $out/t_$name/*/*kernel_stats.csv > $out/r5_${name}_kernel_stats.csv; grep '^{' $out/t_$name.log | tail -1 > $out/r5_${name}_bench_under_trace.json; rm -rf $out/t_$name; head -3 $out/r5_${name}_kernel_stats.csv | cut -c1-70,160-230; }
 tr m14 --mem-conv 14 --rate 7 --slots 8 --steps 2 --warmup 1 --pool 32

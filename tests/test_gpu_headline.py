@@ -1,5 +1,5 @@
 """The benchmark's operating point inside the -m gpu suite (BASELINE.json configs[1] shape): m=11 r=5/6 L=8 msg_len=180
-reads through the DEFAULT 64 read slots, more reads than slots so that slots are refilled while others are mid-read --
+reads through the DEFAULT 128 read slots, more reads than slots so that slots are refilled while others are mid-read --
 every list and score against kernel mode 1 (lva_step_exact: one thread per target, the reference merge verbatim, no
 fingerprints, no lazy messages), three of them against the CPU oracle.  Plus the default path for list sizes above 64
 (lva_step_exact) against the oracle.  Reference: viterbi/viterbi_convolutional_code.cpp:589-858."""
@@ -13,12 +13,12 @@ pytestmark = pytest.mark.gpu
 
 
 def test_benchmark_shape_through_default_slots(oracle):
-    m, r, msg_len, L, md, n = 11, 5, 180, 8, 20, 72
+    m, r, msg_len, L, md, n = 11, 5, 180, 8, 20, 134
     reads = [synth.make_read(m, r, msg_len, 81000 + i, rc=bool(i & 1), margin=3.0 if i % 5 == 0 else 6.0) for i in range(n)]
     posts, rcs = [x["post"] for x in reads], [x["rc"] for x in reads]
     with pkg.Decoder(m, r, msg_len, list_size=L, max_deviation=md) as dec:
         prof = dec.profile()
-        assert prof["kernel"] == 4 and prof["slots"] == 64
+        assert prof["kernel"] == 4 and prof["slots"] == 128
         got = dec.decode(posts, rc=rcs)
     with pkg.Decoder(m, r, msg_len, list_size=L, max_deviation=md, kernel=1, max_slots=24) as dec:
         assert dec.profile()["kernel"] == 1
@@ -27,7 +27,7 @@ def test_benchmark_shape_through_default_slots(oracle):
         assert not isinstance(g, (int, np.integer)) and not isinstance(w, (int, np.integer)), (i, g, w)
         assert np.array_equal(g[0], w[0]), "read %d: list differs from kernel mode 1" % i
         assert np.array_equal(g[1].view(np.uint32), w[1].view(np.uint32)), "read %d: scores differ from kernel mode 1" % i
-    for i in (0, 5, 71):                                   # noisy forward, noisy rc, clean rc
+    for i in (0, 5, 133):                                   # noisy forward, noisy rc, clean rc
         wm, ws = oracle.OracleCode(m, r, msg_len, rc=rcs[i]).decode(posts[i], L, md, num_threads=32)
         assert np.array_equal(got[i][0], wm), "read %d: list differs from the oracle" % i
         assert np.array_equal(got[i][1].view(np.uint32), ws.view(np.uint32)), "read %d: scores differ from the oracle" % i

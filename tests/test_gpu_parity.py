@@ -264,7 +264,7 @@ def test_list_size_one_through_its_default_slots(oracle):
 
 
 def test_default_slot_count_grows_for_small_trellises():
-    for m, r, ml, L, want in ((6, 1, 60, 2, 1024), (8, 1, 100, 2, 256), (11, 1, 40, 2, 64),
+    for m, r, ml, L, want in ((6, 1, 60, 2, 1024), (8, 1, 100, 2, 256), (11, 1, 40, 2, 128),
                               (6, 1, 60, 1, 4096), (8, 1, 100, 1, 1024), (11, 1, 40, 1, 128)):     # L = 1: launches a quarter as long
         with pkg.Decoder(m, r, ml, list_size=L, max_deviation=20) as dec:
             assert dec.profile()["slots"] == want
