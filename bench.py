@@ -355,7 +355,7 @@ def main():
         #      reference merge verbatim, no fingerprints, no lazy messages), outside the timed region ----
         if not a.no_cross_check and prof["kernel"] != 1:
             t1 = time.time()
-            # (a second decoder beside the first: both keep their read slots in HBM -- 2 x 22 GB at the benchmark shape)
+            # (a second decoder beside the first: both keep their read slots in HBM -- 2 x 44 GB at the benchmark shape)
             with pkg.Decoder(a.mem_conv, a.rate, a.msg_len, list_size=a.list_size, max_deviation=a.max_deviation,
                              device=devno, kernel=1) as dec1:
                 bt = batches[last_b]
