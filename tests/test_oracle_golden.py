@@ -1,5 +1,6 @@
 """The CPU oracle against the reference's own outputs (golden fixtures): this is what pins the
 oracle.  No GPU needed."""
+import os
 import numpy as np
 import pytest
 
@@ -74,3 +75,19 @@ def test_bad_parameters_are_refused_like_the_reference(oracle):
         else:
             with pytest.raises(oracle.OracleError):
                 oracle.OracleCode(c["mem_conv"], c["rate"], c["msg_len"])
+
+
+def test_oracle_matches_the_reference_binary_on_random_configurations():
+    """Beyond the fixtures: 30 random configurations (list sizes 1-70, bands down to max_deviation 1, sync markers, ties, NaN / +inf
+    posteriors, truncated reads, refusals) through the unmodified reference binary and through the oracle -- only where the binary
+    exists (the build container; scripts/fuzz_oracle_vs_reference.py is the same draw at any size: 2500 cases in round 5)."""
+    import subprocess
+    import sys
+    from oracle import oracle as O
+    if not O.have_ref():
+        pytest.skip("oracle/_ref/viterbi_nanopore.out not built (needs /root/reference)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_oracle_vs_reference.py"), "7", "30", "--threads", "4"],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "checked 30 bad 0" in p.stdout
