@@ -164,6 +164,10 @@ def main():
     slots = dec.profile()["slots"]
     if dist is not None and backend == "nccl":
         sharding.assert_one_gpu_per_rank(dist)
+    if dist is not None:
+        # the run's one agreement step: same flags, same library build, same code tables on every rank (or every rank leaves)
+        sharding.assert_same_configuration(dist, sharding.configuration_record(a.mem_conv, a.rate, a.msg_len, a.list_size, a.max_deviation,
+                                                                               kernel=a.kernel), device=coll_dev)
 
     # ---- the reads of this rank ------------------------------------------------------------------
     strong = a.total_reads > 0

@@ -17,7 +17,7 @@ ERRORS = {
 
 # every symbol include/lva_decoder.h declares
 EXPORTS = [
-    "lva_version", "lva_abi_version", "lva_strerror", "lva_last_hip_error", "lva_code_describe", "lva_code_tables", "lva_band_table",
+    "lva_version", "lva_abi_version", "lva_strerror", "lva_last_hip_error", "lva_code_describe", "lva_code_tables", "lva_band_table", "lva_lazy_band_words",
     "lva_encode", "lva_algorithmic_bytes", "lva_decoder_create", "lva_decoder_destroy",
     "lva_decode_batch", "lva_decode_batch_device", "lva_decoder_profile", "lva_decoder_set_launch_events", "lva_device_alloc",
     "lva_device_free", "lva_device_upload", "lva_device_synchronize",
@@ -98,6 +98,8 @@ def load_library():
     vp, i32, u32, u64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32, ctypes.c_uint64
     cp = ctypes.c_char_p
     L.lva_version.restype = cp
+    if not hasattr(L, "lva_abi_version"):            # a library built before the ABI carried a version (round 4 and earlier)
+        raise ImportError("%s has no lva_abi_version (ABI version < 5), this package was written for %d: rebuild it" % (path, ABI_VERSION))
     L.lva_abi_version.restype = ctypes.c_int
     if L.lva_abi_version() != ABI_VERSION:
         raise ImportError("%s has ABI version %d, this package was written for %d (struct layouts of include/lva_decoder.h): rebuild it"
@@ -108,6 +110,7 @@ def load_library():
     L.lva_code_describe.argtypes = [i32, i32, u32, i32, cp, u32, ctypes.POINTER(CodeInfoStruct)]
     L.lva_code_tables.argtypes = [i32, i32, u32, i32, cp, u32, vp, vp, vp, vp, vp]
     L.lva_band_table.argtypes = [i32, i32, u32, i32, cp, u32, u32, u32, vp, vp]
+    L.lva_lazy_band_words.argtypes = [i32, i32, u32, i32, cp, u32, u32, u32, u32, vp, vp, vp]
     L.lva_encode.argtypes = [i32, i32, u32, vp, i32, vp]
     L.lva_algorithmic_bytes.argtypes = [i32, i32, u32, i32, cp, u32, u32, u32, u32, ctypes.POINTER(ctypes.c_double)]
     L.lva_decoder_create.argtypes = [ctypes.POINTER(Config), ctypes.POINTER(vp)]

@@ -108,13 +108,15 @@ def decode_rows(args, rows, dec):
 
 
 TMP_PREFIX = ".tmp-"
+_HOST = "".join(ch if ch.isalnum() else "." for ch in (os.uname().nodename or "host"))     # (temporary names say whose they are)
+PUBLISH_BATCH = 256                 # list files flushed and renamed together
 
 
 def write_list_temp(path, msgs):
     """one decoded list under a temporary name beside its final one (never matches OUT_PREFIX_<i>: list consumers take every
     list_*); publish_list_files moves a whole chunk's files into place.  -> (temporary name, final name)"""
     d, base = os.path.split(path)
-    tmp = os.path.join(d, TMP_PREFIX + base + "-%d" % os.getpid())
+    tmp = os.path.join(d, TMP_PREFIX + base + "-%s-%d" % (_HOST, os.getpid()))
     with open(tmp, "w") as f:
         for row in msgs:
             f.write("".join("1" if b else "0" for b in row) + "\n")
@@ -127,20 +129,32 @@ def publish_list_files(pairs):
     every file is written first, then flushed (after the first flush has committed the journal the others find nothing left
     to write), then renamed, then the directory is flushed -- not one write barrier per read: on small trellises the decoder
     produces thousands of lists a second (the reference never flushes at all)."""
-    for tmp, _ in pairs:
-        fd = os.open(tmp, os.O_RDONLY)
-        try:
-            os.fsync(fd)                         # the rename must not become durable before the data
-        finally:
-            os.close(fd)
-    for tmp, path in pairs:
-        os.replace(tmp, path)
-    for d in {os.path.dirname(path) or "." for _, path in pairs}:
-        fd = os.open(d, os.O_RDONLY)
-        try:
-            os.fsync(fd)
-        finally:
-            os.close(fd)
+    published = 0
+    try:
+        for k in range(0, len(pairs), PUBLISH_BATCH):        # (sub-batches: a failure loses a few hundred lists, not a whole chunk)
+            part = pairs[k:k + PUBLISH_BATCH]
+            for tmp, _ in part:
+                fd = os.open(tmp, os.O_RDONLY)
+                try:
+                    os.fsync(fd)                         # the rename must not become durable before the data
+                finally:
+                    os.close(fd)
+            for tmp, path in part:
+                os.replace(tmp, path)
+                published += 1
+            for d in {os.path.dirname(path) or "." for _, path in part}:
+                fd = os.open(d, os.O_RDONLY)
+                try:
+                    os.fsync(fd)
+                finally:
+                    os.close(fd)
+    finally:
+        for tmp, _ in pairs[published:]:                     # whatever was not published does not stay behind
+            try:
+                os.remove(tmp)
+            except OSError:
+                pass
+    return published
 
 
 def write_list_file(path, msgs):
@@ -150,11 +164,12 @@ def write_list_file(path, msgs):
 
 def remove_stale_temp_files(out_prefix):
     """temporary list files a killed run left behind (start-up of every run): exactly the names write_list_temp makes for THIS
-    prefix -- .tmp-<base>_<i>-<pid>, so that a run on prefix `list` leaves `list_b`'s files alone -- and only when the process
-    that made them is gone (a concurrent run on the same prefix may be alive)."""
+    prefix ON THIS HOST -- .tmp-<base>_<i>-<host>-<pid>, so that a run on prefix `list` leaves `list_b`'s files alone and a run
+    on another host that shares the directory keeps its files -- and only when the process that made them is gone (a
+    concurrent run on the same prefix may be alive)."""
     import re
     d, base = os.path.split(out_prefix)
-    pat = re.compile(re.escape(TMP_PREFIX + base) + r"_\d+-(\d+)$")
+    pat = re.compile(re.escape(TMP_PREFIX + base) + r"_\d+-" + re.escape(_HOST) + r"-(\d+)$")
     for name in os.listdir(d or "."):
         mt = pat.match(name)
         if not mt:
@@ -209,11 +224,13 @@ def run(args, out=sys.stdout, dist=None, device=None, coll_dev=None):
                     print("Failure in barcode removing.", file=out)
                 continue       # (other codes: the reference decoder aborts, no output file, on such a read)
             pending.append(write_list_temp(args.out_prefix + "_" + str(i), r[0]))
-            written += 1
-        publish_list_files(pending)
+        written += publish_list_files(pending)
         cursor = max(cursor, upto)
         f_info.flush()
 
+    if dist is not None:       # same flags, same library build, same code tables on every rank (the reference assumes it: merge_lists.py:11-21)
+        sharding.assert_same_configuration(dist, sharding.configuration_record(args.mem_conv, args.rate_conv, args.msg_len, args.list_size,
+                                                                               args.max_deviation), device=coll_dev)
     with Decoder(args.mem_conv, args.rate_conv, args.msg_len, list_size=args.list_size, max_deviation=args.max_deviation,
                  device=args.device if device is None else device) as dec:
         for k in range(0, len(work), chunk):

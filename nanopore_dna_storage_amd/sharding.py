@@ -155,6 +155,57 @@ def assert_one_gpu_per_rank(dist, device="cuda"):
     return sorted(pairs)
 
 
+def configuration_record(mem_conv, rate, msg_len, list_size, max_deviation, sync_marker=None, sync_period=0, kernel=0):
+    """What every rank of a run must agree on, as eight int64: the decoder's configuration, the ABI version and build id of the
+    library this process loaded, and a checksum of the code tables that library builds from the configuration (both
+    orientations: positions, block types, valid-state masks, predecessor tables -- what the kernels index)."""
+    import ctypes
+    import zlib
+    from . import _lib
+    L = _lib.load_library()
+    sm = sync_marker.encode() if sync_marker else None
+    info = _lib.CodeInfoStruct()
+    crc = 0
+    for rc in (0, 1):
+        st = L.lva_code_describe(mem_conv, rate, msg_len, rc, sm, sync_period, ctypes.byref(info))
+        if st != 0:
+            raise _lib.LvaError(st)
+        npos, nconv = info.nstate_pos, info.nstate_conv
+        pos2msg = np.zeros(npos, np.uint32); ptype = np.zeros(npos, np.uint8)
+        vmask = np.zeros(npos, np.uint32); vval = np.zeros(npos, np.uint32); pred = np.zeros(4 * nconv, np.uint16)
+        st = L.lva_code_tables(mem_conv, rate, msg_len, rc, sm, sync_period, pos2msg.ctypes.data, ptype.ctypes.data, vmask.ctypes.data,
+                               vval.ctypes.data, pred.ctypes.data)
+        if st != 0:
+            raise _lib.LvaError(st)
+        for a in (pos2msg, ptype, vmask, vval, pred):
+            crc = zlib.crc32(a.tobytes(), crc)
+    md = int(max_deviation) & 0xFFFFFFFF
+    return [int(mem_conv), int(rate), int(msg_len), int(list_size) | (int(kernel) << 32), md | (int(sync_period) << 32),
+            int(L.lva_abi_version()), zlib.crc32(_lib.build_id().encode()) | (zlib.crc32(sm or b"") << 32) & 0x7FFFFFFFFFFFFFFF, crc]
+
+
+def assert_same_configuration(dist, record, device=None):
+    """The run's one agreement step (the reference ASSUMES identical workers: util/extra/merge_lists.py:11-21 concatenates their
+    lists unchecked): rank 0 broadcasts its configuration_record, every rank compares it with its own -- a stale liblva_hip.so or
+    another list size on one rank would otherwise only show as a wrong or slow shard -- and a MIN all-reduce of the verdicts
+    makes EVERY rank leave with the same SystemExit instead of some of them hanging in the first gather.  Microseconds, before
+    the timed region.  `device`: where the collective's tensors live ("cuda" for nccl/RCCL, None = CPU for gloo)."""
+    import torch
+    if dist is None or not dist.is_initialized():
+        return
+    mine = torch.tensor([int(x) for x in record], dtype=torch.int64, device=device or "cpu")
+    ref = mine.clone()
+    dist.broadcast(ref, src=0)
+    same = bool(torch.equal(ref.cpu(), mine.cpu()))
+    ok = torch.tensor([1 if same else 0], dtype=torch.int64, device=device or "cpu")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) != 1:
+        names = ["mem_conv", "rate", "msg_len", "list_size|kernel", "max_deviation|sync_period", "abi_version", "build_id|sync_marker", "code_tables"]
+        diff = [n for n, a, b in zip(names, ref.cpu().tolist(), mine.cpu().tolist()) if a != b]
+        raise SystemExit("rank %d: the ranks of this run do not agree on the decoder (%s): same flags and the same liblva_hip.so on every rank, please"
+                         % (dist.get_rank(), ("this rank differs from rank 0 in " + ", ".join(diff)) if diff else "another rank differs from rank 0"))
+
+
 def launch_ranks(script, argv, nproc, env=None, capture=False, module=False):
     """Run `script argv...` (`python -m script argv...` when module=True) as `nproc` ranks of one node through torch.distributed.run (one process
     per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) and wait for them.

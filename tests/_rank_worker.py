@@ -40,6 +40,11 @@ def main():
     out_path, mode, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
     dist, rank, world, devno, coll_dev = sharding.init_rank()
     if mode == "fake":
+        if dist is not None and os.environ.get("LVA_TEST_AGREE") == "1":
+            # the run's agreement step; LVA_TEST_ODD_RANK=r: rank r was started with another list size
+            odd = int(os.environ.get("LVA_TEST_ODD_RANK", "-1"))
+            rec = sharding.configuration_record(6, 1, MSG, L + (1 if rank == odd else 0), 20)
+            sharding.assert_same_configuration(dist, rec, device=coll_dev)
         posts, rc = fake_posts(n)
         res = sharding.decode_sharded(fake_decode, posts, rc, L, MSG, dist=dist, device=coll_dev,
                                       shards=sharding.shard_strided(n, world))

@@ -185,3 +185,24 @@ def test_bench_eight_ranks_strong_scaling_arguments(tmp_path):
     z = np.load(dump)
     n = np.array([3 + (gi * 7919) % 57 for gi in range(100000)])                   # the stand-in reads' block counts
     assert np.array_equal(z["counts"], np.where(n < 5, -6, 1 + n % 4))             # every list in global read order, error codes too
+
+
+def test_ranks_that_disagree_all_leave(tmp_path):
+    """The run's agreement step (sharding.assert_same_configuration: rank 0 broadcasts configuration, library build and a checksum
+    of the code tables; a MIN all-reduce spreads the verdict): eight ranks that agree run to the end; with ONE rank started on
+    another list size every rank exits non-zero -- nobody hangs in the first gather (util/extra/merge_lists.py:11-21 assumes
+    identical workers; this checks it)."""
+    import sys
+    import time
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = str(tmp_path / "agree.npz")
+    env = dict(os.environ, LVA_DIST_BACKEND="gloo", LVA_TEST_AGREE="1")
+    assert sharding.launch_ranks(os.path.join(here, "_rank_worker.py"), [out, "fake", "24"], 8, env=env) == 0
+    assert int(np.load(out)["world"]) == 8
+    out2 = str(tmp_path / "disagree.npz")
+    t0 = time.time()
+    rc, _ = sharding.launch_ranks(os.path.join(here, "_rank_worker.py"), [out2, "fake", "24"], 8, env=dict(env, LVA_TEST_ODD_RANK="5"), capture=True)
+    assert rc != 0 and not os.path.exists(out2)
+    assert time.time() - t0 < 120, "the ranks should leave at once, not wait for a collective's time-out"
+    rec = sharding.configuration_record(6, 1, 12, 4, 20)
+    assert len(rec) == 8 and rec != sharding.configuration_record(6, 1, 12, 8, 20) and rec != sharding.configuration_record(8, 1, 12, 4, 20)
