@@ -870,9 +870,9 @@ namespace {
 // Tuning constants, each the measured best of its experiment series (DESIGN_HISTORY.md; the rejected variants are kept as
 // diffs under scripts/experiments/, not as switches in this file).
 constexpr uint32_t TS = TS_TILE;         // source conv states per workgroup tile (workgroup = 8*TS threads); 32 measured 10 % slower
-constexpr int kLazyMinWaves = 8;         // both lazy instances held to 64 registers: four 512-thread workgroups per CU (the anchor
-                                         // instance's own count is 66: one 8-byte spill outside the merge loop, +1.6 % at m=11)
+constexpr int kLazyMinWaves = 6;         // the lazy instances: three 512-thread workgroups per CU (48 KB of LDS each), 80 registers
 constexpr uint32_t kFixupLazyGrid = 4096;   // workgroups (of four wavefronts) of lva_step_fixup_lazy
+constexpr uint32_t kLazyQueue = 160;    // unproven fingerprint matches a workgroup queues (about 50 on the benchmark; more: compared in place)
 constexpr int kLazyInFlight = 2;         // anchor instance: entries whose message loads are in flight together (3: -3 %, 4: -12 %)
 
 
@@ -931,29 +931,12 @@ __device__ __forceinline__ bool fast_output(const Geometry& g, const uint32_t* _
 // The merge proper: decides the new list (scores and fingerprints are stored as it goes) and reports where every accepted
 // entry came from (asrc) and which fingerprint matches still have to be verified on the full message (rej0 / rej1).
 // crow (uniform): 1 = the staged image has the 4 x LL rows of a compact source position (row of crf state kk = kk >> 1).
-// Where the merge finds the 40 log-posteriors of the step.
-struct PostLds {                 // a copy in LDS
-  const float* p;
-  __device__ __forceinline__ float operator()(uint32_t i) const { return p[i]; }
-};
-struct PostLane {                // value i in lane i of one register of the wavefront, fetched with ds_bpermute: no LDS memory (the lazy
-                                 // instances need all of a CU's 160 KB for four workgroups' images).  A lane that is switched off
-                                 // hands out 0, so ALL 64 lanes must be active wherever this is called: the callers keep threads
-                                 // without a target in the wavefront, and the merge loop below runs wavefront-uniform (UNI)
-  float v;
-  __device__ __forceinline__ float operator()(uint32_t i) const {
-    return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(i << 2), __float_as_int(v)));
-  }
-};
-
-// UNI: the loop runs until the LAST lane of the wavefront is done, finished lanes idle inside it (all lanes stay active: PostLane);
-// valid = false: a thread without a target that only keeps the wavefront whole.
-template <int LL, int NL, bool UNI = false, typename PostT = PostLds>
+template <int LL, int NL>
 __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t* __restrict__ prev, uint32_t* __restrict__ cur,
-                                                const uint2* s_src, PostT s_post, uint32_t k, uint32_t c,
+                                                const uint2* s_src, const float* s_post, uint32_t k, uint32_t c,
                                                 uint32_t sc, uint32_t own, uint32_t okmask, uint32_t fpc,
                                                 unsigned long long* o_asrc, unsigned long long* o_rej0, uint32_t* o_lc,
-                                                uint32_t crow = 0, bool valid = true) {
+                                                uint32_t crow = 0) {
   const float NEG = -INFINITY;
   const uint32_t sBlk = g.sBlk;
   const uint32_t row = k >= 4 ? 4u : k;
@@ -962,7 +945,7 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
 
   // the target's own ("stay") list lives in registers, transition score already added
   float st_s[LL]; uint32_t st_h[LL];
-  const float add0 = s_post(row * 8 + k);
+  const float add0 = s_post[row * 8 + k];
   if (okmask & 1u) {
 #pragma unroll
     for (int l = 0; l < LL; ++l) {
@@ -984,9 +967,8 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
   for (int i = 1; i < NL; ++i) {
     const uint32_t kk = list_crf(k, i);
     const uint2 v = s_src[((kk >> crow) * LL) * TS + sc];
-    const float addi = s_post(row * 8 + kk);             // (unconditional: every lane asks)
     const bool ok = ((okmask >> i) & 1u) && u2f(v.x) != NEG;
-    h[i] = ok ? u2f(v.x) + addi : NEG;
+    h[i] = ok ? u2f(v.x) + s_post[row * 8 + kk] : NEG;
     if (ok && !(h[i] > NEG)) why = 2;
   }
 
@@ -1002,8 +984,8 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
 
   // The loop body is written branch-free (selects) except for the store of an accepted entry:
   // lanes that are done keep running harmless iterations until the wavefront's last lane exits.
-  bool go = valid && why == 0;
-  while (UNI ? __builtin_amdgcn_ballot_w64(go) != 0ull : go) {         // :764
+  bool go = why == 0;
+  while (go) {                                                         // :764
     float M = h[0];
 #pragma unroll
     for (int i = 1; i < NL; ++i) M = fmaxf(M, h[i]);
@@ -1019,7 +1001,7 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
 #pragma unroll
     for (int i = 1; i < NL; ++i) last = eq[i] ? (uint32_t)i : last;
     const bool two = sel != last;
-    const bool alive = (M > NEG) && (!UNI || go);   // false: every list exhausted (heap empty) -- or, UNI, a lane that is done and idles
+    const bool alive = M > NEG;            // false: every list exhausted (heap empty)
     const bool proceed = alive && !two;
     const uint32_t j = (ptr >> (4 * sel)) & 15u;
     // source side, computed for every lane (a stay pop reads list 1's slot harmlessly)
@@ -1029,7 +1011,7 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
     const uint32_t fp_src = s_src[at].y ^ fpc;
     const float raw1 = u2f(s_src[has_next ? at + TS : at].x);
     const bool nxt_ok = has_next && raw1 != NEG;
-    const float addk = s_post(row * 8 + kk);                           // unconditional: no branch around one LDS read
+    const float addk = s_post[row * 8 + kk];                           // unconditional: no branch around one LDS read
     const float ns_src = nxt_ok ? raw1 + addk : NEG;                   // :788-796
     const bool is_stay = sel == 0;
     const bool bad = !is_stay && nxt_ok && !(ns_src > NEG);   // overflowed to -inf: the reference would still queue it
@@ -1069,14 +1051,10 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
 #pragma unroll
     for (int i = 0; i < NL; ++i) h[i] = selv(eq[i], ns, h[i]);
     ptr += 1u << (4 * sel);
-    if constexpr (UNI) {                   // (a lane that is done keeps its verdict)
-      why = go ? ((alive && two) ? 1 : ((proceed && bad) ? 2 : (full0 ? 3 : 0))) : why;
-    } else {
-      why = (alive && two) ? 1 : ((proceed && bad) ? 2 : (full0 ? 3 : 0));
-    }
+    why = (alive && two) ? 1 : ((proceed && bad) ? 2 : (full0 ? 3 : 0));
     go = proceed && why == 0 && lc < (uint32_t)LL;
   }
-  if (why || !valid) return why;
+  if (why) return why;
 
   // unused tail of the list (:799)
 #pragma unroll
@@ -1093,7 +1071,7 @@ __device__ __forceinline__ int fast_merge(const Geometry& g, const uint32_t* __r
                                            uint32_t nb, uint32_t fpc, uint32_t np_dst, uint32_t np_src) {
   unsigned long long asrc, rej0;
   uint32_t lc;
-  const int why = fast_merge_core<LL, NL>(g, prev, cur, s_src, PostLds{s_post}, k, c, sc, own, okmask, fpc, &asrc, &rej0, &lc);
+  const int why = fast_merge_core<LL, NL>(g, prev, cur, s_src, s_post, k, c, sc, own, okmask, fpc, &asrc, &rej0, &lc);
   if (why) return why;
   return fast_output<LL, P>(g, prev, cur, k, c, cp, own, src, sh, nb, np_dst, np_src, asrc, rej0, lc) ? 0 : 4;
 }
@@ -1394,21 +1372,23 @@ __device__ __forceinline__ void lz_message(const LzCtx& x, uint32_t p, bool empt
   push_var<2 * P>(mw, S, lz_newbits(x.c, x.m, S));
 }
 
-// 16-bit word index, inside a parity buffer, of the pointer of entry j of conv state `conv` of the list that starts at word `list`:
-// the pointers of a conv state's L entries are adjacent (one 2L-byte store per thread and step)
-__device__ __forceinline__ uint32_t lz_ptr_index(const Geometry& g, uint32_t list, uint32_t j, uint32_t conv) {
-  return (list + g.L * g.sBlk) * 2u + conv * g.L + j;
+// word index, inside a parity buffer, of the 32-bit slot of entry j of conv state `conv` of the list that starts at word `list`
+// (low half: the entry's pointer; high half: its tag, lz_tag): the slots of a conv state's L entries are adjacent (one 4L-byte
+// store per thread and step)
+__device__ __forceinline__ uint32_t lz_slot_index(const Geometry& g, uint32_t list, uint32_t j, uint32_t conv) {
+  return list + g.L * g.sBlk + conv * g.L + j;
 }
 
 // what a time step is in lazy mode
 __device__ __forceinline__ uint32_t lz_class(const Geometry& g, uint32_t t) { return t & (g.lazy - 1u); }           // 0 = anchor (K is 2 or 4)
 __device__ __forceinline__ uint32_t lz_anchor_buf(const Geometry& g, uint32_t t) { return (t >> (g.lazy == 4u ? 2 : 1)) & 1u; }   // message buffer of anchor step t (or of the last anchor before t)
 
-// Where the pointers of a target's candidates come from (uniform over the workgroup but for `own`).
+// Where the pointers of a target's candidates come from (uniform over the workgroup).
 struct LzSrc {
   uint32_t stay_msg, move_msg;   // the row of the stay list / of the source lists carries messages (written by an anchor step, or stale):
                                  // fresh pointers start there; otherwise its entries' stored pointers are composed
   uint32_t stay_kind, move_kind; // ... and where those messages are (0 / 1: message buffer, 2 | parity: spare rows)
+  uint32_t stale;                // the row of the source lists is older than step t-1 (always with messages of its own)
   uint32_t empty;                // time step 0: messages are empty
 };
 __device__ __forceinline__ void lz_src(const Geometry& g, const SlotStep& ss, uint32_t pos, LzSrc* s) {
@@ -1419,96 +1399,190 @@ __device__ __forceinline__ void lz_src(const Geometry& g, const SlotStep& ss, ui
   const uint32_t stale_kind = sk >= 2u ? (2u | (ss.t & 1u)) : sk;    // spare rows of the previous buffer (parity t & 1)
   const bool prev_anchor = cls == 1u || ss.t == 0;
   s->empty = ss.t == 0 ? 1u : 0u;
+  s->stale = stale ? 1u : 0u;
   s->stay_msg = prev_anchor ? 1u : 0u; s->stay_kind = ss.t == 0 ? 0u : fresh;
   s->move_msg = (prev_anchor || stale) ? 1u : 0u; s->move_kind = ss.t == 0 ? 0u : (stale ? stale_kind : fresh);
 }
 
+// the same move on a pointer in its 16-bit memory form (steps between anchors: d stays <= 3, ylow within its six bits)
+__device__ __forceinline__ uint32_t lz16_move(uint32_t st, uint32_t y, uint32_t lz) {
+  const uint32_t d = (st >> 6) & 3u;
+  return st + (1u << 6) + (y << (8u + lz_shift(lz, 1, d)));
+}
+
+// Are the messages behind pointers pa and pb, as they stand in the target, the same?  For code that runs under a per-lane
+// condition (confirmations): both messages are requested TOGETHER, and when every active lane finds the same plane count on
+// both sides -- all but two or three positions of a read -- behind uniform branches only: one round trip per confirmation (a
+// load behind a per-lane branch costs a drain of the memory queue: DESIGN.md, round 5).
+template <int P>
+__device__ __forceinline__ bool lz_same_message(const LzCtx& x, uint32_t pa, uint32_t pb, bool empty) {
+  const uint32_t* ea; const uint32_t* eb; uint32_t ca, cb, na, nb, Sa, Sb;
+  lz_resolve(x, pa, &ea, &ca, &na, &Sa);
+  lz_resolve(x, pb, &eb, &cb, &nb, &Sb);
+  uint32_t ma[2 * P], mb[2 * P];
+#pragma unroll
+  for (int w = 0; w < 2 * P; ++w) { ma[w] = 0; mb[w] = 0; }
+  if (!empty) {
+    const uint32_t n0 = opqs(na);
+    if (__builtin_amdgcn_ballot_w64(na != n0 || nb != n0) == 0ull) {
+      if (n0 == 1) { load_msg_np<P, 1>(ea, x.N, ca, ma); load_msg_np<P, 1>(eb, x.N, cb, mb); }
+      else if (n0 == 2) { load_msg_np<P, 2>(ea, x.N, ca, ma); load_msg_np<P, 2>(eb, x.N, cb, mb); }
+      else if (n0 == 3) { load_msg_np<P, 3>(ea, x.N, ca, ma); load_msg_np<P, 3>(eb, x.N, cb, mb); }
+      else { load_msg_np<P, 4>(ea, x.N, ca, ma); load_msg_np<P, 4>(eb, x.N, cb, mb); }
+    } else {
+      load_msg<P>(ea, x.N, ca, na, ma);
+      load_msg<P>(eb, x.N, cb, nb, mb);
+    }
+  }
+  const uint32_t nbits = __brev(x.c) >> (32u - x.m);
+  push_var<2 * P>(ma, Sa, nbits & ((1u << Sa) - 1u));
+  push_var<2 * P>(mb, Sb, nbits & ((1u << Sb) - 1u));
+  bool same = true;
+#pragma unroll
+  for (int w = 0; w < 2 * P; ++w) same &= (ma[w] == mb[w]);
+  return same;
+}
+
+// The TAG of an entry (high half of its slot, written by EVERY step): where the entry came from one step ago -- list i, index j,
+// as in the merge -- and, when a fingerprint match was CONFIRMED equal to it, where that duplicate came from.
+//   bits 0-5 origin (i << 3 | j), bits 6-11 the confirmed duplicate's origin, bit 12 = there is one
+// Pointers cannot tell that two DIFFERENT stored messages are equal, and that is the common case: the same message lives on
+// paths that differ in when they moved -- chains of them over neighbouring positions -- and such a pair of candidates (the copy
+// that stays in the target, the copy that moves in from below) comes back at every step while both live.  Tags settle it by
+// induction over one step (lz_tag_proof); only pairs that are NEW are compared on their messages.
+__device__ __forceinline__ uint32_t lz_tag(uint32_t a8, uint32_t rec7) { return (a8 & 0x3Fu) | ((rec7 & 0x3Fu) << 6) | ((rec7 & 0x40u) << 6); }
+// Stay candidate with tag ts (an entry of the target's own list) against the candidate that moves in from an entry of source list
+// im with tag tm (the row of that list written by step t-1, as the target's own).  Both rows were merged at step t-1 from the SAME
+// buffer: entry jb of list im of the target's merge then IS entry jb of the stay list of the mover's merge.  The mover is
+// certainly the stay-continuation of that entry if its origin is (0, jb) or its confirmed duplicate's is; the stay candidate is
+// certainly that entry moved in if its origin is (im, jb) or its confirmed duplicate's is.  Both for one jb: the mover, moved in
+// now (same target state, same bits), equals the stay candidate.
+__device__ __forceinline__ bool lz_tag_proof(uint32_t ts, uint32_t tm, uint32_t im) {
+  const uint32_t w0 = (im << 3) | (tm & 7u), w1 = (im << 3) | ((tm >> 6) & 7u);          // what the stay side must name: by origin / by duplicate
+  const bool m0 = ((tm >> 3) & 7u) == 0, m1 = (tm & 0x1000u) && ((tm >> 9) & 7u) == 0;    // the mover stayed / its duplicate did
+  const uint32_t s0 = ts & 0x3Fu, s1 = (ts >> 6) & 0x3Fu;
+  const bool t1 = (ts & 0x1000u) != 0;
+  return (m0 && (s0 == w0 || (t1 && s1 == w0))) || (m1 && (s0 == w1 || (t1 && s1 == w1)));
+}
+
 // Output phase of one target on the lazy path.  false = a fingerprint match did not survive the comparison of the
 // full messages (collision): the exact path redoes the target.
-// CLS: 0 = anchor step (messages stored), 1 = the step after an anchor (every source row carries messages: no stored pointers to
-// compose), 2 = any other step.  own_lo / own_hi: the stored pointers of the target's own (stay) list in the previous buffer,
-// entry j in bits 16 (j & 3) of own_lo (j < 4) / own_hi; s_ptr: those of the source lists, staged as s_src is.
+// CLS: 0 = anchor step (messages stored), 1 = the step after an anchor (every source row carries messages: fresh pointers
+// start there), 2 = any other step.  own[]: the slots of the target's own (stay) list in the previous buffer; s_slot: those of
+// the source lists, staged as s_src is.
 template <int LL, int P, int CLS>
 __device__ __forceinline__ bool lazy_output(const Geometry& g, const LzCtx& x, const LzSrc& sr, uint32_t* __restrict__ cur, uint32_t* __restrict__ mout,
-                                            const uint16_t* s_ptr, uint32_t k, uint32_t own, uint32_t sc, uint32_t y, uint32_t crow,
-                                            unsigned long long own_lo, unsigned long long own_hi, unsigned long long asrc,
-                                            unsigned long long rej0, uint32_t lc) {
+                                            const uint32_t* s_slot, uint32_t k, uint32_t own, uint32_t sc, uint32_t y, uint32_t crow,
+                                            const uint32_t (&ownslot)[LL], unsigned long long asrc, unsigned long long rej0, uint32_t lc,
+                                            uint32_t* s_q, uint32_t* s_qn) {
   bool good = true;
   const bool empty = opqs(sr.empty) != 0;
-  // the pointer of candidate (list i, index j) of the previous step AS AN ENTRY OF THE TARGET
-  auto cand = [&](uint32_t i, uint32_t j) __attribute__((always_inline)) -> uint32_t {
+  // An unproven match: the two pointers (register form) go to the workgroup's queue -- compared on their messages after the
+  // workgroup's merges by whole wavefronts (lva_step_lazy's tail): about one match in nine is unproven, so nearly every
+  // wavefront has some, and a wavefront that compares them itself pays a round of gathers for a handful of active lanes.
+  // Queue full: compared here.
+  auto defer = [&](uint32_t pa, uint32_t pb) __attribute__((always_inline)) {
+    const uint32_t at = atomicAdd(s_qn, 1u);
+    if (at < kLazyQueue) { s_q[3 * at] = pa; s_q[3 * at + 1] = pb; s_q[3 * at + 2] = x.c | (k << 16); }
+    else good &= lz_same_message<P>(x, pa, pb, empty);
+  };
+  // the slot of candidate (list i, index j) of the previous step
+  auto slot_own = [&](uint32_t j) __attribute__((always_inline)) -> uint32_t {
+    uint32_t v = opq(ownslot[0]);
+#pragma unroll
+    for (int u = 1; u < LL; ++u) v = j == (uint32_t)u ? opq(ownslot[u]) : v;
+    return v;
+  };
+  auto slot_src = [&](uint32_t i, uint32_t j) __attribute__((always_inline)) -> uint32_t {
+    return s_slot[((list_crf(k, i) >> crow) * TS + sc) * LL + j];
+  };
+  // the pointer (memory form) of candidate (list i, index j) AS AN ENTRY OF THE TARGET
+  auto cand16 = [&](uint32_t i, uint32_t j) __attribute__((always_inline)) -> uint32_t {
     if (i == 0) {
       if (CLS == 1 || opqs(sr.stay_msg)) return lz_synth(j, k, opqs(sr.stay_kind));
-      const unsigned long long w = sel(j >= 4u, own_hi, own_lo);
-      return lz_unpack((uint32_t)(w >> (16u * (j & 3u))) & 0xFFFFu);
+      return slot_own(j) & 0xFFFFu;
     }
-    const uint32_t kk = list_crf(k, i);
     uint32_t p;
-    if (CLS == 1 || opqs(sr.move_msg)) p = lz_synth(j, kk, opqs(sr.move_kind));
-    else p = lz_unpack(s_ptr[((kk >> crow) * TS + sc) * LL + j]);
-    return lz_move(p, y, opqs(x.lz));
+    if (CLS == 1 || opqs(sr.move_msg)) p = lz_synth(j, list_crf(k, i), opqs(sr.move_kind));
+    else p = slot_src(i, j) & 0xFFFFu;
+    return lz16_move(p, y, opqs(x.lz));
   };
-  if constexpr (CLS != 0) {
-    // ---- a step between anchors: one pointer per accepted entry; messages are touched only where a fingerprint match pairs
-    //      two DIFFERENT pointers ----
-    uint32_t pk[LL / 2];
-#pragma unroll
-    for (int l = 0; l < LL / 2; ++l) pk[l] = 0;
-#pragma unroll
-    for (int l = 0; l < LL; ++l) {
-      if ((uint32_t)l < lc) {
-        const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu;
-        pk[l >> 1] |= lz_pack(cand(a8 >> 3, a8 & 7u)) << (16 * (l & 1));
-      }
-    }
-    uint16_t* dst = reinterpret_cast<uint16_t*>(cur) + lz_ptr_index(g, own, 0, x.c);
-    if constexpr (LL == 8) *reinterpret_cast<lva_u32x4*>(dst) = lva_u32x4{pk[0], pk[1], pk[2], pk[3]};
-    else if constexpr (LL == 4) *reinterpret_cast<lva_u32x2*>(dst) = lva_u32x2{pk[0], pk[1]};
-    else *reinterpret_cast<uint32_t*>(dst) = pk[0];
-    // fingerprint matches: a loop over the entries that HAVE one (about one per target).  Equal pointers: the same stored
-    // message under the same shift -- confirmed.  The others are compared on the full messages in a second loop, so that a
-    // wavefront pays the gathers once for its unproven pairs instead of once per match.
-    uint32_t todo = 0, slow = 0;
+  // Fingerprint matches, one per accepted entry at most (rej0), in a loop over the entries that HAVE one (about one per target).
+  // One candidate stays, one moves in, the row below not stale, not step 0 (whose rows carry no tags): the two slots are read
+  // once -- proven by their tags, or their pointers go to the queue.  Anything else (two movers: 5 in 100 000): to the queue.
+  const bool tags_ok = !opqs(sr.stale) && !empty;
+  auto ptr_of = [&](uint32_t i, uint32_t j, uint32_t sw) __attribute__((always_inline)) -> uint32_t {   // register form, from the candidate's slot word
+    if (i == 0) return lz_unpack((CLS == 1 || opqs(sr.stay_msg)) ? lz_synth(j, k, opqs(sr.stay_kind)) : sw & 0xFFFFu);
+    return lz_move(lz_unpack((CLS == 1 || opqs(sr.move_msg)) ? lz_synth(j, list_crf(k, i), opqs(sr.move_kind)) : sw & 0xFFFFu), y, opqs(x.lz));
+  };
+  {
+    uint32_t todo = 0;
 #pragma unroll
     for (int l = 0; l < LL; ++l) todo |= ((uint32_t)(rej0 >> (7 * l + 6)) & 1u) << l;
     while (todo) {
       const uint32_t l = (uint32_t)__builtin_ctz(todo);
       todo &= todo - 1u;
       const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0x3Fu, rec = (uint32_t)(rej0 >> (7 * l)) & 0x3Fu;
-      slow |= (cand(a8 >> 3, a8 & 7u) != cand(rec >> 3, rec & 7u) ? 1u : 0u) << l;
+      const uint32_t ia = a8 >> 3, ir = rec >> 3;
+      if (tags_ok && (ia == 0) != (ir == 0)) {
+        const uint32_t st = ia == 0 ? a8 : rec, mv = ia == 0 ? rec : a8;       // (which is the stay candidate differs per lane)
+        const uint32_t so = slot_own(st & 7u), sm = slot_src(mv >> 3, mv & 7u);
+        if (!lz_tag_proof(so >> 16, sm >> 16, mv >> 3)) defer(ptr_of(0u, st & 7u, so), ptr_of(mv >> 3, mv & 7u, sm));
+      } else {
+        // (the staged slots are only there when the row below is not stale -- then fresh pointers start at its entries anyway)
+        const uint32_t sa = ia == 0 ? slot_own(a8 & 7u) : (tags_ok ? slot_src(ia, a8 & 7u) : 0u);
+        const uint32_t sb = ir == 0 ? slot_own(rec & 7u) : (tags_ok ? slot_src(ir, rec & 7u) : 0u);
+        defer(ptr_of(ia, a8 & 7u, sa), ptr_of(ir, rec & 7u, sb));
+      }
     }
-    while (slow) {
-      const uint32_t l = (uint32_t)__builtin_ctz(slow);
-      slow &= slow - 1u;
-      const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0x3Fu, rec = (uint32_t)(rej0 >> (7 * l)) & 0x3Fu;
-      uint32_t ma[2 * P], mb[2 * P];
-      lz_message<P>(x, cand(a8 >> 3, a8 & 7u), empty, ma);
-      lz_message<P>(x, cand(rec >> 3, rec & 7u), empty, mb);
+  }
+  // the slots of the new entries: tag (every step) and pointer (steps between anchors)
+  {
+    uint32_t sl[LL];
 #pragma unroll
-      for (int w = 0; w < 2 * P; ++w) good &= (ma[w] == mb[w]);
+    for (int l = 0; l < LL; ++l) {
+      sl[l] = 0;
+      if ((uint32_t)l < lc) {
+        const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu;
+        sl[l] = lz_tag(a8, (uint32_t)(rej0 >> (7 * l)) & 0x7Fu) << 16;
+        if constexpr (CLS != 0) sl[l] |= cand16(a8 >> 3, a8 & 7u);
+      }
     }
+    uint32_t* dst = cur + lz_slot_index(g, own, 0, x.c);
+#pragma unroll
+    for (int l = 0; l < LL; l += 4) {
+      if constexpr (LL >= 4) *reinterpret_cast<lva_u32x4*>(dst + l) = lva_u32x4{sl[l], sl[l + 1], sl[l + 2], sl[l + 3]};
+      else *reinterpret_cast<lva_u32x2*>(dst) = lva_u32x2{sl[0], sl[1]};
+    }
+  }
+  if constexpr (CLS != 0) {
+    // ---- a step between anchors: no message is touched here (unproven matches: the queue) ----
     return good;
   } else {
     // ---- anchor step: ONE gather per accepted entry (its pointer names the stored message), shifted and stored coalesced;
     //      kLazyInFlight entries in flight ----
     // (four message planes: one entry in flight -- 8 more message registers would cost the anchor instance a wavefront per SIMD;
     //  measured at m=14: 4.91 against 4.69 reads/s)
+    auto cand = [&](uint32_t i, uint32_t j) __attribute__((always_inline)) -> uint32_t {      // register form: one more move than a slot holds
+      if (i == 0) return lz_unpack(opqs(sr.stay_msg) ? lz_synth(j, k, opqs(sr.stay_kind)) : slot_own(j) & 0xFFFFu);
+      const uint32_t p = opqs(sr.move_msg) ? lz_synth(j, list_crf(k, i), opqs(sr.move_kind)) : slot_src(i, j) & 0xFFFFu;
+      return lz_move(lz_unpack(p), y, opqs(x.lz));
+    };
     constexpr int GBW = P >= 4 ? 1 : kLazyInFlight;
     constexpr int GB = LL >= GBW ? GBW : LL;
 #pragma unroll
     for (int l0 = 0; l0 < LL; l0 += GB) {
-      uint32_t m[GB][2 * P], pa[GB], sv[GB];
+      uint32_t m[GB][2 * P], sv[GB];
 #pragma unroll
       for (int u = 0; u < GB; ++u) {
         const int l = l0 + u;
-        pa[u] = 0; sv[u] = 0;
+        sv[u] = 0;
 #pragma unroll
         for (int w = 0; w < 2 * P; ++w) m[u][w] = 0;
         if ((uint32_t)l < lc) {
           const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu;
-          pa[u] = cand(a8 >> 3, a8 & 7u);
           const uint32_t* ent; uint32_t conv, np;
-          lz_resolve(x, pa[u], &ent, &conv, &np, &sv[u]);
+          lz_resolve(x, cand(a8 >> 3, a8 & 7u), &ent, &conv, &np, &sv[u]);
           if (!empty) load_msg<P>(ent, x.N, conv, np, m[u]);
         }
       }
@@ -1518,16 +1592,6 @@ __device__ __forceinline__ bool lazy_output(const Geometry& g, const LzCtx& x, c
         if ((uint32_t)l < lc) {
           push_var<2 * P>(m[u], sv[u], lz_newbits(x.c, x.m, sv[u]));
           store_msg<P>(mout + own + l * x.sBlk + x.pw, x.N, x.c, (opqs(x.lz) >> 16) & 7u, m[u]);
-          const uint32_t rec = (uint32_t)(rej0 >> (7 * l)) & 0x7Fu;
-          if (rec & 0x40u) {                                   // the match filed under this entry: the same pointer, or the same message
-            const uint32_t pr = cand((rec >> 3) & 7u, rec & 7u);
-            if (pr != pa[u]) {
-              uint32_t qm[2 * P];
-              lz_message<P>(x, pr, empty, qm);
-#pragma unroll
-              for (int w = 0; w < 2 * P; ++w) good &= (qm[w] == m[u][w]);
-            }
-          }
         }
       }
     }
@@ -1540,14 +1604,19 @@ __device__ __forceinline__ bool lazy_output(const Geometry& g, const LzCtx& x, c
 // grid / block as lva_step_fast.  Three instances: CLS = 0 serves the slots at an anchor step (t % K == 0), 1 those at the
 // step after one, 2 the others; the host keeps every slot of a decoder at the same class (reads start on launches that are
 // multiples of K), so a launch runs ONE instance over all slots.  Steps between anchors keep the merge's small register
-// footprint (no message in flight); only the anchor instance gathers messages.
+// footprint (no message in flight); only the anchor instance gathers messages.  LDS: 32 KB of list heads + 16 KB of slots:
+// three workgroups per CU (four with 8 KB of pointers alone and the posteriors in a register: 8 % faster where nothing else
+// changed, but without the tags half of the fingerprint matches had to be compared on their messages -- measured, round 6).
 template <int LL, int P, int CLS>
 __global__ __launch_bounds__(8 * TS, kLazyMinWaves) void lva_step_lazy(StepArgs args, Geometry g, const DevCode* __restrict__ codes,
                                                      uint32_t* __restrict__ trellis, WorkHdr* __restrict__ hdr,
                                                      uint32_t* __restrict__ items) {
   __shared__ uint2 s_src[8 * LL * TS];
-  __shared__ uint32_t s_ptrw[CLS != 1 ? 8 * LL * TS / 2 : 1];     // (32 + 8 KB at L = 8: four workgroups fill a CU's 160 KB exactly --
-                                                                   //  the 40 posteriors live in a register of every wavefront, PostLane)
+  __shared__ uint32_t s_slot[8 * LL * TS];
+  __shared__ float s_post[40];
+  __shared__ uint32_t s_q[3 * kLazyQueue];       // unproven fingerprint matches of the workgroup (lazy_output's defer)
+  __shared__ uint32_t s_qn;
+  if (threadIdx.x == 0) s_qn = 0;
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
     hdr->count[args.step_parity ^ 1u] = 0;     // the other parity's list was consumed by the last fix-up
     hdr->overflow[args.step_parity ^ 1u] = 0;
@@ -1576,20 +1645,18 @@ __global__ __launch_bounds__(8 * TS, kLazyMinWaves) void lva_step_lazy(StepArgs 
       const float s = u2f(prev[own_c]) + ss.post_row[(k >= 4 ? 4u : k) * 8 + k];
       cur[own_c] = f2u(s);
       cur[own_c + 1] = prev[own_c + 1];
-      if (CLS == 0) { mout[own + 2 * N + 2 * c] = 0u; mout[own + 2 * N + 2 * c + 1] = 0u; }
-      else {                               // stay, entry 0: a fresh pointer after an anchor, the entry's own pointer otherwise
-        const uint16_t* pp = reinterpret_cast<const uint16_t*>(prev);
-        reinterpret_cast<uint16_t*>(cur)[lz_ptr_index(g, own, 0, c)] =
-            sr.stay_msg ? (uint16_t)lz_pack(lz_synth(0u, k, sr.stay_kind)) : pp[lz_ptr_index(g, own, 0, c)];
-      }
+      uint32_t* slot0 = cur + lz_slot_index(g, own, 0, c);
+      if (CLS == 0) { mout[own + 2 * N + 2 * c] = 0u; mout[own + 2 * N + 2 * c + 1] = 0u; *slot0 = lz_tag(0u, 0u) << 16; }
+      else           // stay, entry 0: a fresh pointer after an anchor, the entry's own pointer otherwise
+        *slot0 = (lz_tag(0u, 0u) << 16) | (sr.stay_msg ? lz_synth(0u, k, sr.stay_kind) : prev[lz_slot_index(g, own, 0, c)] & 0xFFFFu);
       for (int l = 1; l < LL; ++l) cur[own_c + l * g.sBlk] = kNegInfBits;
     }
     return;
   }
 
   if (!tile_has_target(args, cd, pos, tile)) return;     // (first / last positions: most tiles have no valid target)
-  // ---- stage the (score, fingerprint) pairs of 64 source conv states (and, where the source rows carry pointers, those):
-  //      8 crf lists, or the 4 compact lists of a one-bit source position (all of them data) ----
+  // ---- stage the (score, fingerprint) pairs of 64 source conv states and the slots of their entries (nothing the target can use
+  //      when the row is stale): 8 crf lists, or the 4 compact lists of a one-bit source position (all of them data) ----
   const uint32_t src = (uint32_t)((uint64_t)((pos - 1) % g.R) * 8 * g.sCrf);
   const uint32_t crow = source_compact(g, cd, ss, blockIdx.y, pos);
   const uint32_t nrow = 8u >> crow;
@@ -1599,51 +1666,59 @@ __global__ __launch_bounds__(8 * TS, kLazyMinWaves) void lva_step_lazy(StepArgs 
                                                     2 * (tile * TS) + 4 * lane2);
     *reinterpret_cast<uint4*>(&s_src[rowi * TS + 2 * lane2]) = v;
   }
-  if (CLS != 1 && !sr.move_msg) {         // per crf: the L pointers of 64 conv states = 2 TS LL contiguous bytes
-    constexpr uint32_t kW = TS * LL / 2;   // words per crf
-    for (uint32_t chunk = tid; chunk < nrow * kW; chunk += 8u * TS) {
-      const uint32_t kk = chunk / kW, w = chunk % kW;
-      s_ptrw[kk * kW + w] = prev[src + (uint64_t)kk * g.sCrf + (uint64_t)LL * g.sBlk + (tile * TS * LL) / 2 + w];
+  if (!sr.stale && !sr.empty) {           // per crf: the L slots of 64 conv states = 4 TS LL contiguous bytes
+    constexpr uint32_t kQ = TS * LL / 4;   // 16-byte pieces per crf
+    for (uint32_t chunk = tid; chunk < nrow * kQ; chunk += 8u * TS) {
+      const uint32_t kk = chunk / kQ, q = chunk % kQ;
+      *reinterpret_cast<uint4*>(&s_slot[kk * TS * LL + 4 * q]) =
+          *reinterpret_cast<const uint4*>(prev + src + (uint64_t)kk * g.sCrf + (uint64_t)LL * g.sBlk + tile * TS * LL + 4 * q);
     }
   }
-  PostLane post;                          // posterior i of the step in lane i of every wavefront
-  post.v = (tid & 63u) < 40u ? LVA_GLOBAL(float, ss.post_row)[tid & 63u] : 0.0f;
+  if (tid < 40) s_post[tid] = LVA_GLOBAL(float, ss.post_row)[tid];
   __syncthreads();
 
-  // Threads without a target stay (with nothing to merge and nothing to store) as long as their wavefront has one: PostLane
-  // needs every lane active.  (Wavefronts 0-3 hold the flip targets, 4-7 the flop targets: k < 4 is uniform per wavefront.)
+  LzCtx x;
+  lz_ctx(cd, g, slot_base, pos, 0u, &x);
   TileTarget t;
-  t.c = 0; t.cp = 0; t.sc = 0; t.k = (tid / (4 * TS)) * 4; t.sh = 1; t.nb = 0; t.fpc = 0; t.np_dst = 1; t.np_src = 1; t.ok = 0; t.own = 0;
-  t.base = 0; t.reach = 0; t.pk1 = 0; t.c0 = 0;
-  const bool valid = tile_target<TS>(cd, g, ss, pos, tile, tid, &t);
-  if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;
-  if (!valid) { t.ok = 0; t.sc = 0; t.k = (tid / (4 * TS)) * 4; }
+  const bool has_target = tile_target<TS>(cd, g, ss, pos, tile, tid, &t);
   unsigned long long asrc = 0, rej0 = 0;
   uint32_t lc = 0;
-  int why = t.k < 4 ? fast_merge_core<LL, 8, true>(g, prev, cur, s_src, post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &lc, crow, valid)
-                    : fast_merge_core<LL, 2, true>(g, prev, cur, s_src, post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &lc, crow, valid);
-  if (!valid) return;
-  if (!why) {
-    LzCtx x;
-    lz_ctx(cd, g, slot_base, pos, t.c, &x);
+  int why = 0;
+  if (has_target)
+    why = t.k < 4 ? fast_merge_core<LL, 8>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &lc, crow)
+                  : fast_merge_core<LL, 2>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &lc, crow);
+  if (has_target && !why) {
+    x.c = t.c;
     const uint32_t y = t.cp & ((1u << t.sh) - 1u);       // the register bits the move into (pos, c) lost
-    // the stored pointers of the target's own (stay) list (requested here, not ahead of the merge: four registers that would have
-    // to live through its loop are four registers spilled)
-    unsigned long long own_lo = 0, own_hi = 0;
-    if (CLS != 1 && !sr.stay_msg && (t.ok & 1u)) {
-      const uint16_t* pp = reinterpret_cast<const uint16_t*>(prev) + lz_ptr_index(g, t.own, 0, t.c);
-      if constexpr (LL == 8) { const lva_u32x4 v = *LVA_GLOBAL(lva_u32x4, pp); own_lo = ((unsigned long long)v.y << 32) | v.x; own_hi = ((unsigned long long)v.w << 32) | v.z; }
-      else if constexpr (LL == 4) { const lva_u32x2 v = *LVA_GLOBAL(lva_u32x2, pp); own_lo = ((unsigned long long)v.y << 32) | v.x; }
-      else own_lo = *LVA_GLOBAL(uint32_t, pp);
+    // the slots of the target's own (stay) list (requested here, not ahead of the merge: registers that would have to live
+    // through its loop are registers spilled)
+    uint32_t ownslot[LL];
+#pragma unroll
+    for (int l = 0; l < LL; ++l) ownslot[l] = 0;
+    if (!sr.empty && (t.ok & 1u)) {
+      const uint32_t* pp = prev + lz_slot_index(g, t.own, 0, t.c);
+      if constexpr (LL >= 4) {
+#pragma unroll
+        for (int l = 0; l < LL; l += 4) { const lva_u32x4 v = *LVA_GLOBAL(lva_u32x4, pp + l); ownslot[l] = v.x; ownslot[l + 1] = v.y; ownslot[l + 2] = v.z; ownslot[l + 3] = v.w; }
+      } else { const lva_u32x2 v = *LVA_GLOBAL(lva_u32x2, pp); ownslot[0] = v.x; ownslot[1] = v.y; }
     }
-    if (!lazy_output<LL, P, CLS>(g, x, sr, cur, mout, reinterpret_cast<const uint16_t*>(s_ptrw), t.k, t.own, t.sc, y, crow, own_lo, own_hi,
-                                 asrc, rej0, lc)) why = 4;
+    if (!lazy_output<LL, P, CLS>(g, x, sr, cur, mout, s_slot, t.k, t.own, t.sc, y, crow, ownslot, asrc, rej0, lc, s_q, &s_qn)) why = 4;
   }
-  if (why) {
-    atomicAdd(&hdr->reason[why - 1], 1ull);
+  auto to_work_list = [&](int reason, uint32_t k, uint32_t c) __attribute__((always_inline)) {
+    atomicAdd(&hdr->reason[reason - 1], 1ull);
     const uint32_t idx = atomicAdd(&hdr->count[args.step_parity], 1u);
-    if (idx < hdr->cap) items[idx] = make_item(cd.m, blockIdx.z, blockIdx.y, t.k, t.c);
+    if (idx < hdr->cap) items[idx] = make_item(cd.m, blockIdx.z, blockIdx.y, k, c);
     else hdr->overflow[args.step_parity] = 1u;
+  };
+  if (why) to_work_list(why, t.k, t.c);
+  // ---- the workgroup's unproven fingerprint matches, compared on their messages by whole wavefronts: a pair that differs is a
+  //      collision, its target goes to the exact path (which rewrites whatever the fast path stored for it) ----
+  __syncthreads();
+  const uint32_t nq = s_qn < kLazyQueue ? s_qn : kLazyQueue;
+  for (uint32_t e = tid; e < nq; e += 8u * TS) {
+    const uint32_t w2 = s_q[3 * e + 2];
+    x.c = w2 & 0xFFFFu;
+    if (!lz_same_message<P>(x, s_q[3 * e], s_q[3 * e + 1], sr.empty != 0)) to_work_list(4, w2 >> 16, w2 & 0xFFFFu);
   }
 }
 
@@ -1712,7 +1787,7 @@ __global__ __launch_bounds__(256) void lva_step_fixup_lazy(StepArgs args, Geomet
         cs = u2f(v.x); cy = i != 0 ? v.y ^ tg.fpc : v.y;
         const bool msg_row = i == 0 ? sr.stay_msg != 0 : sr.move_msg != 0;
         uint32_t p = lz_synth(j, kk, i == 0 ? sr.stay_kind : sr.move_kind);
-        if (!msg_row) p = lz_unpack(reinterpret_cast<const uint16_t*>(prev)[lz_ptr_index(g, lst, j, cv)]);
+        if (!msg_row) p = lz_unpack(prev[lz_slot_index(g, lst, j, cv)] & 0xFFFFu);
         cb = i == 0 ? p : lz_move(p, ymove, x.lz);
       }
     }
@@ -1810,8 +1885,9 @@ __global__ __launch_bounds__(256) void lva_step_fixup_lazy(StepArgs args, Geomet
           for (int u = 0; u < 2 * P; ++u) wv2 = w == (uint32_t)u ? mw[u] : wv2;
         }
         if (e < l && w < Wd) mout[tg.own + e * sBlk + 2 * g.N + msg_word_off(g.N, tg.c, w, tg.np_dst)] = wv2;
+        if (e < l && w == 0) cur[lz_slot_index(g, tg.own, e, tg.c)] = lz_tag((li << 3) | lj, 0u) << 16;   // (tag: origin only)
       } else if (e < l && w == 0) {
-        reinterpret_cast<uint16_t*>(cur)[lz_ptr_index(g, tg.own, e, tg.c)] = (uint16_t)lz_pack(p1);
+        cur[lz_slot_index(g, tg.own, e, tg.c)] = lz_pack(p1) | (lz_tag((li << 3) | lj, 0u) << 16);
       }
     }
   }
@@ -1847,12 +1923,12 @@ __global__ __launch_bounds__(256) void lva_lazy_spare_rows(StepArgs args, Geomet
   const uint32_t spare = (uint32_t)(((uint64_t)(g.R + pos % g.RS) * 8 + lst) * g.sCrf);
   LzCtx x;
   lz_ctx(cd, g, slot_base, pos, c, &x);
-  const uint16_t* pp = reinterpret_cast<const uint16_t*>(cur) + lz_ptr_index(g, own, 0, c);
+  const uint32_t* pp = cur + lz_slot_index(g, own, 0, c);
   const uint32_t np_dst = cd.npair[pos];
   for (uint32_t l = 0; l < g.L; ++l) {
     if (cur[own + l * g.sBlk + 2 * c] == kNegInfBits) break;          // (:799: the unused tail of a list)
     uint32_t mw[2 * P];
-    lz_message<P>(x, lz_unpack(pp[l]), false, mw);
+    lz_message<P>(x, lz_unpack(pp[l] & 0xFFFFu), false, mw);
     store_msg<P>(cur + spare + l * g.sBlk + 2 * g.N, g.N, c, np_dst, mw);
   }
 }
@@ -2552,7 +2628,7 @@ __global__ void lva_gather_final(Geometry g, const DevCode* __restrict__ codes, 
             for (uint32_t f = 2; f < g.F; ++f) w[f] = msg_word(g, mb, own + l * g.sBlk, c, f - 2, cd.npair[pos]);
           } else {                               // the entry's pointer names the stored message it descends from
             uint32_t mw[8];
-            lz_message<4>(x, lz_unpack(reinterpret_cast<const uint16_t*>(buf)[lz_ptr_index(g, own, l, c)]), false, mw);
+            lz_message<4>(x, lz_unpack(buf[lz_slot_index(g, own, l, c)] & 0xFFFFu), false, mw);
             for (uint32_t f = 2; f < g.F; ++f) w[f] = mw[f - 2];
           }
         }
