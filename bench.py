@@ -61,6 +61,8 @@ def parse(argv=None):
     ap.add_argument("--no-cross-check", action="store_true", help="skip the exact-kernel check of the last timed batch")
     ap.add_argument("--cross-check-reads", type=int, default=0, help="check only the first K reads of the last timed batch (0 = all)")
     ap.add_argument("--dump-lists", type=str, default="", help="rank 0 writes the gathered lists of the last step (npz)")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the short driver-timed runs of configs[3] and configs[4]")
+    ap.add_argument("--extra-reads", type=int, default=32, help="reads per extra configuration")
     return ap.parse_args(argv)
 
 
@@ -133,6 +135,38 @@ class StubDecoder:
 
     def close(self):
         pass
+
+
+def run_extra_config(pkg, synth, np, name, m, r, L, golden, n_reads, devno, build_id):
+    """One short, driver-timed run of another BASELINE.json configuration at the decoder's DEFAULT slot count: n_reads reads in one
+    lva_decode_batch call (the first of them golden fixtures of the reference binary, checked), HIP events around every launch."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_util as G
+    posts, rcs, want = [], [], []
+    for g in golden:
+        meta, post, lines = G.load_case(g)
+        posts.append(post); rcs.append(bool(meta["rc"])); want.append(lines)
+    for i in range(max(0, n_reads - len(golden))):
+        x = synth.make_read(m, r, MSG_LEN, seed=5000 + i, rc=bool(i & 1), margin=3.0 if i % 5 == 0 else 6.0)
+        posts.append(x["post"]); rcs.append(x["rc"])
+    with pkg.Decoder(m, r, MSG_LEN, list_size=L, max_deviation=MAXDEV, device=devno) as d2:
+        d2.decode(posts[:2], rc=rcs[:2])                      # (first call: allocations, code upload)
+        d2.set_launch_events(True)
+        t0 = time.perf_counter()
+        out = d2.decode(posts, rc=rcs)
+        dt = time.perf_counter() - t0
+        p = d2.profile()
+    for i, w in enumerate(want):
+        assert as_lines(out[i]) == w, "%s: list of golden read %s differs from the reference's" % (name, golden[i])
+    dom = p["dominant_kernel_ms"]
+    return {"workload": "%s: mem_conv=%d rate=%d list_size=%d msg_len=%d max_deviation=%d, %d reads in one lva_decode_batch call, %d read slots (the decoder's default)"
+                        % (name, m, r, L, MSG_LEN, MAXDEV, len(posts), p["slots"]),
+            "reads_s": len(posts) / dt, "avg_launch_ms": dom / max(p["timed_launches"], 1), "launches": p["step_launches"],
+            "mean_active_slots": p["read_steps"] / max(p["step_launches"], 1),
+            "achieved": (p["algorithmic_bytes"] / 1e9) / (dom / 1e3) if dom > 0 else None,
+            "frac": (p["algorithmic_bytes"] / 1e9) / (dom / 1e3) / 8000.0 if dom > 0 else None,
+            "pair_avg_launch_ms": p["step_pair_ms"] / max(p["timed_launches"], 1),
+            "golden_checked": list(golden), "kernel_mode": p["kernel"], "slots": p["slots"], "build_id": build_id}
 
 
 def main():
@@ -221,6 +255,7 @@ def main():
 
     step_no = 0
     outs = {}
+    dec_closed = False
     for _ in range(a.warmup):
         outs[step_no % nbatch] = run(batches[step_no % nbatch]); step_no += 1
     dec.set_launch_events(not a.no_launch_events)
@@ -302,9 +337,9 @@ def main():
         dom_ms = acc["dom_ms"] if use_events else acc["span_ms"]
         achieved = (acc["alg"] / 1e9) / (dom_ms / 1e3) if dom_ms > 0 else 0.0
         kname = {2: "lva_step_fast<%d,P>" % a.list_size if a.list_size in (2, 4, 8) else ("lva_step_acs<P>" if a.list_size == 1 else "lva_step_big<LL,P> / lva_step_big_rec<LL>"),
-                 4: "lva_step_lazy<%d,P,true> | lva_step_lazy<%d,P,false> (the anchor-step and the odd-step instance: the slots are "
-                    "phase-aligned, so even launches run the first over all slots and odd launches the second; avg_launch_ms is the "
-                    "mean over both kinds of launch)" % (a.list_size, a.list_size),
+                 4: "lva_step_lazy<%d,P,0> | <%d,P,1> | <%d,P,2> (anchor step every fourth launch -- messages stored --, the step after it, "
+                    "the other two: the slots are phase-aligned, so a launch runs ONE instance over all slots; avg_launch_ms is the "
+                    "mean over all launches)" % (a.list_size, a.list_size, a.list_size),
                  3: "lva_step_wave", 1: "lva_step_exact"}.get(prof["kernel"], "?")
         # HBM bytes per launch from this round's PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
         # passes, scripts/pmc_mem.sh), per read-step, scaled to this run's mean number of active slots per launch
@@ -379,6 +414,19 @@ def main():
             res["config"]["cross_checked_reads"] = len(want)
             res["config"]["cross_check"] = "%s %d lists + scores of the last timed batch == kernel mode 1 (lva_step_exact), %.1f s" % (
                 "all" if k == len(bt["reads"]) else "the first", len(want), time.time() - t1)
+        # ---- configs[3] and configs[4] of BASELINE.json, one short driver-timed run each at the decoder's default slot count (the
+        #      headline decoder is closed first: every decoder keeps its read slots resident in HBM) ----
+        if (world == 1 and not stub and not a.no_extra_configs
+                and (a.mem_conv, a.rate, a.list_size, a.msg_len, a.max_deviation) == (M, RATE, LIST, MSG_LEN, MAXDEV)):
+            if a.resident:
+                for bt in batches:
+                    dec.free(bt["dev"])
+                a.resident = False
+            dec.close()
+            dec_closed = True
+            res["extra_configs"] = [
+                run_extra_config(pkg, synth, np, "configs[3]", 14, 7, 8, ["m14_r7_L8", "m14_r7_L8_rc"], a.extra_reads, devno, build_id),
+                run_extra_config(pkg, synth, np, "configs[4]", 11, 5, 64, ["m11_r5_L64", "m11_r5_L64_rc"], a.extra_reads, devno, build_id)]
         if cpu is not None:
             O = cpu["O"]
             # the -t 1 sample runs beside the -t N samples: N is capped so that N + 1 threads never exceed the host's CPUs
@@ -423,10 +471,11 @@ def main():
                                            sample="1 read, %d threads; wall %.1f s" % (cores, wall))
             res["config"]["reference_checked_reads"] = checked
         print(json.dumps(res), flush=True)
-    if a.resident:
-        for bt in batches:
-            dec.free(bt["dev"])
-    dec.close()
+    if not dec_closed:
+        if a.resident:
+            for bt in batches:
+                dec.free(bt["dev"])
+        dec.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -110,7 +110,8 @@ def load_library():
     L.lva_code_describe.argtypes = [i32, i32, u32, i32, cp, u32, ctypes.POINTER(CodeInfoStruct)]
     L.lva_code_tables.argtypes = [i32, i32, u32, i32, cp, u32, vp, vp, vp, vp, vp]
     L.lva_band_table.argtypes = [i32, i32, u32, i32, cp, u32, u32, u32, vp, vp]
-    L.lva_lazy_band_words.argtypes = [i32, i32, u32, i32, cp, u32, u32, u32, u32, vp, vp, vp]
+    if hasattr(L, "lva_lazy_band_words") or not os.environ.get("LVA_LIB_PATH"):       # (LVA_LIB_PATH: an older build in a head-to-head run)
+        L.lva_lazy_band_words.argtypes = [i32, i32, u32, i32, cp, u32, u32, u32, u32, vp, vp, vp]
     L.lva_encode.argtypes = [i32, i32, u32, vp, i32, vp]
     L.lva_algorithmic_bytes.argtypes = [i32, i32, u32, i32, cp, u32, u32, u32, u32, ctypes.POINTER(ctypes.c_double)]
     L.lva_decoder_create.argtypes = [ctypes.POINTER(Config), ctypes.POINTER(vp)]

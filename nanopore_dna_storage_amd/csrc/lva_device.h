@@ -26,7 +26,7 @@
 //     (< npos - nblk + t): the host clips the band table of every step to that range
 //     (lva_api.cpp decode_impl), and "outside the band" already reads as -inf / is never used.
 //   * variants of this layout, selected per decoder (Geometry below): compact lists at one-bit
-//     positions (cmp: 4 lists per ring position there), 32-bit slots (message pointer, tag) behind every list
+//     positions (cmp: 4 lists per ring position there), 16-bit message pointers behind every list
 //     (lazy), and [conv][entry] records instead of planes for long lists (rec).
 //
 // Message fingerprint: XOR over the set message bits of a fixed pseudo-random 32-bit word per
@@ -149,8 +149,8 @@ inline Geometry make_geometry(uint32_t N, uint32_t L, uint32_t msg_bits, uint32_
   g.lazy = lazy; g.RS = lazy ? RS : 0u; g.rec = (rec && !lazy && g.P == 3 && L >= 32 && L % 4 == 0) ? 1u : 0u;   // (below 32 entries the plane layout is faster: measured)
   g.cmp = ((lazy || cmp) && !g.rec) ? 1u : 0u;       // (the record layout keeps a list's entries together: a list that does not exist is a hole of whole lines)
   g.sBlk = N * g.F;
-  // lazy mode: behind the L entry blocks of a (ring, crf) list, L 32-bit slots per conv state ([conv][entry]: pointer | tag << 16)
-  g.sCrf = (uint64_t)g.sBlk * L + (lazy ? (uint64_t)N * L : 0); g.sRing = g.sCrf * 8;
+  // lazy mode: behind the L entry blocks of a (ring, crf) list, L 16-bit pointers per conv state ([conv][entry])
+  g.sCrf = (uint64_t)g.sBlk * L + (lazy ? (uint64_t)N * L / 2 : 0); g.sRing = g.sCrf * 8;
   g.sPar = g.sRing * (R + g.RS); g.sSlot = g.sPar * 2;
   return g;
 }

@@ -872,7 +872,7 @@ namespace {
 constexpr uint32_t TS = TS_TILE;         // source conv states per workgroup tile (workgroup = 8*TS threads); 32 measured 10 % slower
 constexpr int kLazyMinWaves = 6;         // the lazy instances: three 512-thread workgroups per CU (48 KB of LDS each), 80 registers
 constexpr uint32_t kFixupLazyGrid = 4096;   // workgroups (of four wavefronts) of lva_step_fixup_lazy
-constexpr uint32_t kLazyQueue = 160;    // unproven fingerprint matches a workgroup queues (about 50 on the benchmark; more: compared in place)
+constexpr uint32_t kLazyQueue = 640;    // unproven fingerprint matches a workgroup queues (more: compared in place)
 constexpr int kLazyInFlight = 2;         // anchor instance: entries whose message loads are in flight together (3: -3 %, 4: -12 %)
 
 
@@ -1372,11 +1372,10 @@ __device__ __forceinline__ void lz_message(const LzCtx& x, uint32_t p, bool empt
   push_var<2 * P>(mw, S, lz_newbits(x.c, x.m, S));
 }
 
-// word index, inside a parity buffer, of the 32-bit slot of entry j of conv state `conv` of the list that starts at word `list`
-// (low half: the entry's pointer; high half: its tag, lz_tag): the slots of a conv state's L entries are adjacent (one 4L-byte
-// store per thread and step)
+// 16-bit word index, inside a parity buffer, of the pointer of entry j of conv state `conv` of the list that starts at word `list`:
+// the pointers of a conv state's L entries are adjacent (one 2L-byte store per thread and step)
 __device__ __forceinline__ uint32_t lz_slot_index(const Geometry& g, uint32_t list, uint32_t j, uint32_t conv) {
-  return list + g.L * g.sBlk + conv * g.L + j;
+  return (list + g.L * g.sBlk) * 2u + conv * g.L + j;
 }
 
 // what a time step is in lazy mode
@@ -1402,6 +1401,15 @@ __device__ __forceinline__ void lz_src(const Geometry& g, const SlotStep& ss, ui
   s->stale = stale ? 1u : 0u;
   s->stay_msg = prev_anchor ? 1u : 0u; s->stay_kind = ss.t == 0 ? 0u : fresh;
   s->move_msg = (prev_anchor || stale) ? 1u : 0u; s->move_kind = ss.t == 0 ? 0u : (stale ? stale_kind : fresh);
+}
+
+// Word offset from a list of row `pos` of the buffer step t writes to its copy in the spare rows (modulo 2^32: added to an offset
+// inside a parity buffer), or 0 when `pos` is not the row the host marked for copying at this step (SlotStep.flags: a later step
+// reads it stale).  Never at an anchor step, whose rows carry messages anyway.
+__device__ __forceinline__ uint32_t lz_spare_delta(const Geometry& g, const SlotStep& ss, uint32_t pos) {
+  const uint32_t mat = (ss.flags >> kLzMatShift) & 3u;
+  if (!mat || pos != ss.lo + mat - 1u || lz_class(g, ss.t) == 0) return 0u;
+  return (uint32_t)(((uint64_t)(g.R + pos % g.RS) - (uint64_t)(pos % g.R)) * 8u * g.sCrf);
 }
 
 // the same move on a pointer in its 16-bit memory form (steps between anchors: d stays <= 3, ylow within its six bits)
@@ -1443,131 +1451,140 @@ __device__ __forceinline__ bool lz_same_message(const LzCtx& x, uint32_t pa, uin
   return same;
 }
 
-// The TAG of an entry (high half of its slot, written by EVERY step): where the entry came from one step ago -- list i, index j,
-// as in the merge -- and, when a fingerprint match was CONFIRMED equal to it, where that duplicate came from.
-//   bits 0-5 origin (i << 3 | j), bits 6-11 the confirmed duplicate's origin, bit 12 = there is one
-// Pointers cannot tell that two DIFFERENT stored messages are equal, and that is the common case: the same message lives on
-// paths that differ in when they moved -- chains of them over neighbouring positions -- and such a pair of candidates (the copy
-// that stays in the target, the copy that moves in from below) comes back at every step while both live.  Tags settle it by
-// induction over one step (lz_tag_proof); only pairs that are NEW are compared on their messages.
-__device__ __forceinline__ uint32_t lz_tag(uint32_t a8, uint32_t rec7) { return (a8 & 0x3Fu) | ((rec7 & 0x3Fu) << 6) | ((rec7 & 0x40u) << 6); }
-// Stay candidate with tag ts (an entry of the target's own list) against the candidate that moves in from an entry of source list
-// im with tag tm (the row of that list written by step t-1, as the target's own).  Both rows were merged at step t-1 from the SAME
-// buffer: entry jb of list im of the target's merge then IS entry jb of the stay list of the mover's merge.  The mover is
-// certainly the stay-continuation of that entry if its origin is (0, jb) or its confirmed duplicate's is; the stay candidate is
-// certainly that entry moved in if its origin is (im, jb) or its confirmed duplicate's is.  Both for one jb: the mover, moved in
-// now (same target state, same bits), equals the stay candidate.
-__device__ __forceinline__ bool lz_tag_proof(uint32_t ts, uint32_t tm, uint32_t im) {
-  const uint32_t w0 = (im << 3) | (tm & 7u), w1 = (im << 3) | ((tm >> 6) & 7u);          // what the stay side must name: by origin / by duplicate
-  const bool m0 = ((tm >> 3) & 7u) == 0, m1 = (tm & 0x1000u) && ((tm >> 9) & 7u) == 0;    // the mover stayed / its duplicate did
-  const uint32_t s0 = ts & 0x3Fu, s1 = (ts >> 6) & 0x3Fu;
-  const bool t1 = (ts & 0x1000u) != 0;
-  return (m0 && (s0 == w0 || (t1 && s1 == w0))) || (m1 && (s0 == w1 || (t1 && s1 == w1)));
-}
-
 // Output phase of one target on the lazy path.  false = a fingerprint match did not survive the comparison of the
 // full messages (collision): the exact path redoes the target.
 // CLS: 0 = anchor step (messages stored), 1 = the step after an anchor (every source row carries messages: fresh pointers
-// start there), 2 = any other step.  own[]: the slots of the target's own (stay) list in the previous buffer; s_slot: those of
-// the source lists, staged as s_src is.
+// start there), 2 = any other step.  own_lo / own_hi: the pointers of the target's own (stay) list in the previous buffer, entry j in
+// bits 16 (j & 3) of own_lo (j < 4) / own_hi; s_ptr: those of the source lists, staged as s_src is.
 template <int LL, int P, int CLS>
 __device__ __forceinline__ bool lazy_output(const Geometry& g, const LzCtx& x, const LzSrc& sr, uint32_t* __restrict__ cur, uint32_t* __restrict__ mout,
-                                            const uint32_t* s_slot, uint32_t k, uint32_t own, uint32_t sc, uint32_t y, uint32_t crow,
-                                            const uint32_t (&ownslot)[LL], unsigned long long asrc, unsigned long long rej0, uint32_t lc,
-                                            uint32_t* s_q, uint32_t* s_qn) {
+                                            const uint16_t* s_ptr, uint32_t k, uint32_t own, uint32_t sc, uint32_t y, uint32_t crow,
+                                            unsigned long long own_lo, unsigned long long own_hi, unsigned long long asrc,
+                                            unsigned long long rej0, uint32_t lc, uint32_t* s_q, uint32_t* s_qn, uint32_t spare) {
   bool good = true;
   const bool empty = opqs(sr.empty) != 0;
   // An unproven match: the two pointers (register form) go to the workgroup's queue -- compared on their messages after the
-  // workgroup's merges by whole wavefronts (lva_step_lazy's tail): about one match in nine is unproven, so nearly every
-  // wavefront has some, and a wavefront that compares them itself pays a round of gathers for a handful of active lanes.
-  // Queue full: compared here.
+  // workgroup's merges by whole wavefronts (lva_step_lazy's tail): a wavefront that compares its own pays a round of gathers and
+  // some 150 instructions per match of its busiest lane, for a handful of active lanes.  Queue full: compared here.
   auto defer = [&](uint32_t pa, uint32_t pb) __attribute__((always_inline)) {
     const uint32_t at = atomicAdd(s_qn, 1u);
     if (at < kLazyQueue) { s_q[3 * at] = pa; s_q[3 * at + 1] = pb; s_q[3 * at + 2] = x.c | (k << 16); }
     else good &= lz_same_message<P>(x, pa, pb, empty);
   };
-  // the slot of candidate (list i, index j) of the previous step
-  auto slot_own = [&](uint32_t j) __attribute__((always_inline)) -> uint32_t {
-    uint32_t v = opq(ownslot[0]);
-#pragma unroll
-    for (int u = 1; u < LL; ++u) v = j == (uint32_t)u ? opq(ownslot[u]) : v;
-    return v;
-  };
-  auto slot_src = [&](uint32_t i, uint32_t j) __attribute__((always_inline)) -> uint32_t {
-    return s_slot[((list_crf(k, i) >> crow) * TS + sc) * LL + j];
-  };
-  // the pointer (memory form) of candidate (list i, index j) AS AN ENTRY OF THE TARGET
+  // the pointer (memory form) of candidate (list i, index j) AS AN ENTRY OF THE TARGET; lz_unpack of it: register form
   auto cand16 = [&](uint32_t i, uint32_t j) __attribute__((always_inline)) -> uint32_t {
     if (i == 0) {
       if (CLS == 1 || opqs(sr.stay_msg)) return lz_synth(j, k, opqs(sr.stay_kind));
-      return slot_own(j) & 0xFFFFu;
+      const unsigned long long w = sel(j >= 4u, own_hi, own_lo);
+      return (uint32_t)(w >> (16u * (j & 3u))) & 0xFFFFu;
     }
     uint32_t p;
     if (CLS == 1 || opqs(sr.move_msg)) p = lz_synth(j, list_crf(k, i), opqs(sr.move_kind));
-    else p = slot_src(i, j) & 0xFFFFu;
+    else p = s_ptr[((list_crf(k, i) >> crow) * TS + sc) * LL + j];
     return lz16_move(p, y, opqs(x.lz));
   };
-  // Fingerprint matches, one per accepted entry at most (rej0), in a loop over the entries that HAVE one (about one per target).
-  // One candidate stays, one moves in, the row below not stale, not step 0 (whose rows carry no tags): the two slots are read
-  // once -- proven by their tags, or their pointers go to the queue.  Anything else (two movers: 5 in 100 000): to the queue.
-  const bool tags_ok = !opqs(sr.stale) && !empty;
-  auto ptr_of = [&](uint32_t i, uint32_t j, uint32_t sw) __attribute__((always_inline)) -> uint32_t {   // register form, from the candidate's slot word
-    if (i == 0) return lz_unpack((CLS == 1 || opqs(sr.stay_msg)) ? lz_synth(j, k, opqs(sr.stay_kind)) : sw & 0xFFFFu);
-    return lz_move(lz_unpack((CLS == 1 || opqs(sr.move_msg)) ? lz_synth(j, list_crf(k, i), opqs(sr.move_kind)) : sw & 0xFFFFu), y, opqs(x.lz));
+  // ... and with the one move more than a stored pointer holds that an anchor step may compose (register form)
+  auto cand = [&](uint32_t i, uint32_t j) __attribute__((always_inline)) -> uint32_t {
+    if (i == 0) {
+      if (opqs(sr.stay_msg)) return lz_synth(j, k, opqs(sr.stay_kind));
+      const unsigned long long w = sel(j >= 4u, own_hi, own_lo);
+      return lz_unpack((uint32_t)(w >> (16u * (j & 3u))) & 0xFFFFu);
+    }
+    const uint32_t p = opqs(sr.move_msg) ? lz_synth(j, list_crf(k, i), opqs(sr.move_kind)) : s_ptr[((list_crf(k, i) >> crow) * TS + sc) * LL + j];
+    return lz_move(lz_unpack(p), y, opqs(x.lz));
   };
-  {
-    uint32_t todo = 0;
+  uint32_t todo = 0;
 #pragma unroll
-    for (int l = 0; l < LL; ++l) todo |= ((uint32_t)(rej0 >> (7 * l + 6)) & 1u) << l;
+  for (int l = 0; l < LL; ++l) todo |= ((uint32_t)(rej0 >> (7 * l + 6)) & 1u) << l;
+  if constexpr (CLS != 0) {
+    // ---- a step between anchors: one pointer per accepted entry; no message is touched here ----
+    uint32_t pk[LL / 2];
+#pragma unroll
+    for (int l = 0; l < LL / 2; ++l) pk[l] = 0;
+#pragma unroll
+    for (int l = 0; l < LL; ++l) {
+      if ((uint32_t)l < lc) {
+        const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu;
+        pk[l >> 1] |= cand16(a8 >> 3, a8 & 7u) << (16 * (l & 1));
+      }
+    }
+    // Fingerprint matches, one per accepted entry at most (rej0), in a loop over the entries that HAVE one (about one per target).
+    //   proven   both candidates carry the same pointer: one stored message under one shift.  Otherwise the pair goes to the queue.
+    //   re-base  when the stay candidate survives a match with a candidate that moves in, the entry is given the MOVER's pointer
+    //            (both name the same message): such a pair comes back at every step while both paths live -- the stay entry
+    //            stays, the mover's source entry stays below and moves in again -- and is then proven by pointer equality.
     while (todo) {
       const uint32_t l = (uint32_t)__builtin_ctz(todo);
       todo &= todo - 1u;
       const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0x3Fu, rec = (uint32_t)(rej0 >> (7 * l)) & 0x3Fu;
-      const uint32_t ia = a8 >> 3, ir = rec >> 3;
-      if (tags_ok && (ia == 0) != (ir == 0)) {
-        const uint32_t st = ia == 0 ? a8 : rec, mv = ia == 0 ? rec : a8;       // (which is the stay candidate differs per lane)
-        const uint32_t so = slot_own(st & 7u), sm = slot_src(mv >> 3, mv & 7u);
-        if (!lz_tag_proof(so >> 16, sm >> 16, mv >> 3)) defer(ptr_of(0u, st & 7u, so), ptr_of(mv >> 3, mv & 7u, sm));
-      } else {
-        // (the staged slots are only there when the row below is not stale -- then fresh pointers start at its entries anyway)
-        const uint32_t sa = ia == 0 ? slot_own(a8 & 7u) : (tags_ok ? slot_src(ia, a8 & 7u) : 0u);
-        const uint32_t sb = ir == 0 ? slot_own(rec & 7u) : (tags_ok ? slot_src(ir, rec & 7u) : 0u);
-        defer(ptr_of(ia, a8 & 7u, sa), ptr_of(ir, rec & 7u, sb));
+      if constexpr (CLS == 1) {
+        // Right after an anchor both candidates' messages are ONE hop away, in rows the anchor wrote: the stay candidate's in the
+        // target's own list, the mover's one position below -- planes in use, buffers and the move are uniform over the workgroup,
+        // which candidate is which differs per lane.  Both are requested together behind uniform branches only and compared here
+        // (no pointer can prove such a pair: every entry of an anchor's rows is its own stored message).
+        if (((a8 >> 3) == 0) != ((rec >> 3) == 0) && !empty) {
+          const uint32_t st = (a8 >> 3) == 0 ? a8 : rec, mv = (a8 >> 3) == 0 ? rec : a8;
+          const uint32_t lz = opqs(x.lz), npa = (lz >> 16) & 7u, npb = (lz >> 19) & 7u, cm1 = (lz >> 9) & 1u;
+          const uint32_t* Ma = opqs(sr.stay_kind) & 1u ? opqs(x.M1) : opqs(x.M0);
+          const uint32_t mk = opqs(sr.move_kind);
+          const uint32_t* Mb = mk & 1u ? opqs(x.M1) : opqs(x.M0);
+          uint32_t rb = opqs(x.rp) - 1u; rb += (int32_t)rb < 0 ? opqs(x.R) : 0u;
+          if (mk & 2u) { rb = opqs(x.rsp) - 1u; rb += (int32_t)rb < 0 ? opqs(x.RS) : 0u; rb += opqs(x.R); }     // (stale row: its copy in the spare rows)
+          const uint32_t S = lz_shift(lz, 0, 1u);
+          uint32_t ma[2 * P], mb[2 * P];
+          load_msg<P>(Ma + own + mul24(st & 7u, x.sBlk) + x.pw, x.N, x.c, npa, ma);
+          load_msg<P>(Mb + mul24(rb * 8u + (list_crf(k, mv >> 3) >> cm1), x.sCrf) + mul24(mv & 7u, x.sBlk) + x.pw, x.N,
+                      ((x.c << S) | y) & (x.N - 1u), npb, mb);
+          push_var<2 * P>(mb, S, lz_newbits(x.c, x.m, S));
+#pragma unroll
+          for (int w = 0; w < 2 * P; ++w) good &= (ma[w] == mb[w]);
+          if ((a8 >> 3) == 0) {                               // re-base entry l onto the mover's pointer
+            const uint32_t pr = cand16(rec >> 3, rec & 7u);
+            const uint32_t sh = 16u * (l & 1u), keep = ~(0xFFFFu << sh);
+#pragma unroll
+            for (int w = 0; w < LL / 2; ++w) pk[w] = (l >> 1) == (uint32_t)w ? ((pk[w] & keep) | (pr << sh)) : pk[w];
+          }
+          continue;
+        }
+      }
+      const uint32_t pa = cand16(a8 >> 3, a8 & 7u), pr = cand16(rec >> 3, rec & 7u);
+      if (pa != pr) defer(lz_unpack(pa), lz_unpack(pr));
+      if ((a8 >> 3) == 0 && (rec >> 3) != 0) {              // re-base entry l onto the mover's pointer
+        const uint32_t sh = 16u * (l & 1u), keep = ~(0xFFFFu << sh);
+#pragma unroll
+        for (int w = 0; w < LL / 2; ++w) pk[w] = (l >> 1) == (uint32_t)w ? ((pk[w] & keep) | (pr << sh)) : pk[w];
       }
     }
-  }
-  // the slots of the new entries: tag (every step) and pointer (steps between anchors)
-  {
-    uint32_t sl[LL];
+    uint16_t* dst = reinterpret_cast<uint16_t*>(cur) + lz_slot_index(g, own, 0, x.c);
+    if constexpr (LL == 8) *reinterpret_cast<lva_u32x4*>(dst) = lva_u32x4{pk[0], pk[1], pk[2], pk[3]};
+    else if constexpr (LL == 4) *reinterpret_cast<lva_u32x2*>(dst) = lva_u32x2{pk[0], pk[1]};
+    else *reinterpret_cast<uint32_t*>(dst) = pk[0];
+    // The row the host marked (SlotStep.flags; one per slot and step at most -- uniform over the workgroup) will be read STALE by a
+    // later step, whose entries could not compose pointers of another generation: its messages are resolved now and stored in the
+    // spare row  R + pos % RS  of the buffer this step writes; readers of the stale row start fresh pointers there.
+    if (opqs(spare) != 0u) {                               // (spare: word offset from a list of the row to its copy, 0 = not this row)
 #pragma unroll
-    for (int l = 0; l < LL; ++l) {
-      sl[l] = 0;
-      if ((uint32_t)l < lc) {
-        const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu;
-        sl[l] = lz_tag(a8, (uint32_t)(rej0 >> (7 * l)) & 0x7Fu) << 16;
-        if constexpr (CLS != 0) sl[l] |= cand16(a8 >> 3, a8 & 7u);
+      for (int l = 0; l < LL; ++l) {
+        if ((uint32_t)l < lc) {
+          uint32_t mw[2 * P];
+          lz_message<P>(x, lz_unpack((pk[l >> 1] >> (16 * (l & 1))) & 0xFFFFu), empty, mw);
+          store_msg<P>(cur + own + opqs(spare) + l * x.sBlk + x.pw, x.N, x.c, (opqs(x.lz) >> 16) & 7u, mw);
+        }
       }
     }
-    uint32_t* dst = cur + lz_slot_index(g, own, 0, x.c);
-#pragma unroll
-    for (int l = 0; l < LL; l += 4) {
-      if constexpr (LL >= 4) *reinterpret_cast<lva_u32x4*>(dst + l) = lva_u32x4{sl[l], sl[l + 1], sl[l + 2], sl[l + 3]};
-      else *reinterpret_cast<lva_u32x2*>(dst) = lva_u32x2{sl[0], sl[1]};
-    }
-  }
-  if constexpr (CLS != 0) {
-    // ---- a step between anchors: no message is touched here (unproven matches: the queue) ----
     return good;
   } else {
     // ---- anchor step: ONE gather per accepted entry (its pointer names the stored message), shifted and stored coalesced;
     //      kLazyInFlight entries in flight ----
     // (four message planes: one entry in flight -- 8 more message registers would cost the anchor instance a wavefront per SIMD;
     //  measured at m=14: 4.91 against 4.69 reads/s)
-    auto cand = [&](uint32_t i, uint32_t j) __attribute__((always_inline)) -> uint32_t {      // register form: one more move than a slot holds
-      if (i == 0) return lz_unpack(opqs(sr.stay_msg) ? lz_synth(j, k, opqs(sr.stay_kind)) : slot_own(j) & 0xFFFFu);
-      const uint32_t p = opqs(sr.move_msg) ? lz_synth(j, list_crf(k, i), opqs(sr.move_kind)) : slot_src(i, j) & 0xFFFFu;
-      return lz_move(lz_unpack(p), y, opqs(x.lz));
-    };
+    while (todo) {                                           // matches: the same pointer, or to the queue
+      const uint32_t l = (uint32_t)__builtin_ctz(todo);
+      todo &= todo - 1u;
+      const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0x3Fu, rec = (uint32_t)(rej0 >> (7 * l)) & 0x3Fu;
+      const uint32_t pa = cand(a8 >> 3, a8 & 7u), pr = cand(rec >> 3, rec & 7u);
+      if (pa != pr) defer(pa, pr);
+    }
     constexpr int GBW = P >= 4 ? 1 : kLazyInFlight;
     constexpr int GB = LL >= GBW ? GBW : LL;
 #pragma unroll
@@ -1612,7 +1629,7 @@ __global__ __launch_bounds__(8 * TS, kLazyMinWaves) void lva_step_lazy(StepArgs 
                                                      uint32_t* __restrict__ trellis, WorkHdr* __restrict__ hdr,
                                                      uint32_t* __restrict__ items) {
   __shared__ uint2 s_src[8 * LL * TS];
-  __shared__ uint32_t s_slot[8 * LL * TS];
+  __shared__ __attribute__((aligned(16))) uint32_t s_ptrw[8 * LL * TS / 2];
   __shared__ float s_post[40];
   __shared__ uint32_t s_q[3 * kLazyQueue];       // unproven fingerprint matches of the workgroup (lazy_output's defer)
   __shared__ uint32_t s_qn;
@@ -1645,18 +1662,22 @@ __global__ __launch_bounds__(8 * TS, kLazyMinWaves) void lva_step_lazy(StepArgs 
       const float s = u2f(prev[own_c]) + ss.post_row[(k >= 4 ? 4u : k) * 8 + k];
       cur[own_c] = f2u(s);
       cur[own_c + 1] = prev[own_c + 1];
-      uint32_t* slot0 = cur + lz_slot_index(g, own, 0, c);
-      if (CLS == 0) { mout[own + 2 * N + 2 * c] = 0u; mout[own + 2 * N + 2 * c + 1] = 0u; *slot0 = lz_tag(0u, 0u) << 16; }
-      else           // stay, entry 0: a fresh pointer after an anchor, the entry's own pointer otherwise
-        *slot0 = (lz_tag(0u, 0u) << 16) | (sr.stay_msg ? lz_synth(0u, k, sr.stay_kind) : prev[lz_slot_index(g, own, 0, c)] & 0xFFFFu);
+      if (CLS == 0) { mout[own + 2 * N + 2 * c] = 0u; mout[own + 2 * N + 2 * c + 1] = 0u; }
+      else {           // stay, entry 0: a fresh pointer after an anchor, the entry's own pointer otherwise
+        const uint16_t* pp = reinterpret_cast<const uint16_t*>(prev);
+        reinterpret_cast<uint16_t*>(cur)[lz_slot_index(g, own, 0, c)] =
+            sr.stay_msg ? (uint16_t)lz_synth(0u, k, sr.stay_kind) : pp[lz_slot_index(g, own, 0, c)];
+        const uint32_t spare = lz_spare_delta(g, ss, 0u);    // (row 0 marked for the spare rows: the empty message)
+        if (spare) { cur[own + spare + 2 * N + 2 * c] = 0u; cur[own + spare + 2 * N + 2 * c + 1] = 0u; }
+      }
       for (int l = 1; l < LL; ++l) cur[own_c + l * g.sBlk] = kNegInfBits;
     }
     return;
   }
 
   if (!tile_has_target(args, cd, pos, tile)) return;     // (first / last positions: most tiles have no valid target)
-  // ---- stage the (score, fingerprint) pairs of 64 source conv states and the slots of their entries (nothing the target can use
-  //      when the row is stale): 8 crf lists, or the 4 compact lists of a one-bit source position (all of them data) ----
+  // ---- stage the (score, fingerprint) pairs of 64 source conv states and, where their row carries pointers, those:
+  //      8 crf lists, or the 4 compact lists of a one-bit source position (all of them data) ----
   const uint32_t src = (uint32_t)((uint64_t)((pos - 1) % g.R) * 8 * g.sCrf);
   const uint32_t crow = source_compact(g, cd, ss, blockIdx.y, pos);
   const uint32_t nrow = 8u >> crow;
@@ -1666,12 +1687,19 @@ __global__ __launch_bounds__(8 * TS, kLazyMinWaves) void lva_step_lazy(StepArgs 
                                                     2 * (tile * TS) + 4 * lane2);
     *reinterpret_cast<uint4*>(&s_src[rowi * TS + 2 * lane2]) = v;
   }
-  if (!sr.stale && !sr.empty) {           // per crf: the L slots of 64 conv states = 4 TS LL contiguous bytes
-    constexpr uint32_t kQ = TS * LL / 4;   // 16-byte pieces per crf
-    for (uint32_t chunk = tid; chunk < nrow * kQ; chunk += 8u * TS) {
-      const uint32_t kk = chunk / kQ, q = chunk % kQ;
-      *reinterpret_cast<uint4*>(&s_slot[kk * TS * LL + 4 * q]) =
-          *reinterpret_cast<const uint4*>(prev + src + (uint64_t)kk * g.sCrf + (uint64_t)LL * g.sBlk + tile * TS * LL + 4 * q);
+  if (CLS != 1 && !sr.move_msg) {         // per crf: the L pointers of 64 conv states = 2 TS LL contiguous bytes
+    constexpr uint32_t kW = TS * LL / 2;   // words per crf
+    if constexpr (kW % 4 == 0) {
+      for (uint32_t chunk = tid; chunk < nrow * (kW / 4); chunk += 8u * TS) {
+        const uint32_t kk = chunk / (kW / 4), q = chunk % (kW / 4);
+        *reinterpret_cast<uint4*>(&s_ptrw[kk * kW + 4 * q]) =
+            *reinterpret_cast<const uint4*>(prev + src + (uint64_t)kk * g.sCrf + (uint64_t)LL * g.sBlk + (tile * TS * LL) / 2 + 4 * q);
+      }
+    } else {
+      for (uint32_t chunk = tid; chunk < nrow * kW; chunk += 8u * TS) {
+        const uint32_t kk = chunk / kW, w = chunk % kW;
+        s_ptrw[kk * kW + w] = prev[src + (uint64_t)kk * g.sCrf + (uint64_t)LL * g.sBlk + (tile * TS * LL) / 2 + w];
+      }
     }
   }
   if (tid < 40) s_post[tid] = LVA_GLOBAL(float, ss.post_row)[tid];
@@ -1690,19 +1718,17 @@ __global__ __launch_bounds__(8 * TS, kLazyMinWaves) void lva_step_lazy(StepArgs 
   if (has_target && !why) {
     x.c = t.c;
     const uint32_t y = t.cp & ((1u << t.sh) - 1u);       // the register bits the move into (pos, c) lost
-    // the slots of the target's own (stay) list (requested here, not ahead of the merge: registers that would have to live
+    // the pointers of the target's own (stay) list (requested here, not ahead of the merge: registers that would have to live
     // through its loop are registers spilled)
-    uint32_t ownslot[LL];
-#pragma unroll
-    for (int l = 0; l < LL; ++l) ownslot[l] = 0;
-    if (!sr.empty && (t.ok & 1u)) {
-      const uint32_t* pp = prev + lz_slot_index(g, t.own, 0, t.c);
-      if constexpr (LL >= 4) {
-#pragma unroll
-        for (int l = 0; l < LL; l += 4) { const lva_u32x4 v = *LVA_GLOBAL(lva_u32x4, pp + l); ownslot[l] = v.x; ownslot[l + 1] = v.y; ownslot[l + 2] = v.z; ownslot[l + 3] = v.w; }
-      } else { const lva_u32x2 v = *LVA_GLOBAL(lva_u32x2, pp); ownslot[0] = v.x; ownslot[1] = v.y; }
+    unsigned long long own_lo = 0, own_hi = 0;
+    if (CLS != 1 && !sr.stay_msg && (t.ok & 1u)) {
+      const uint16_t* pp = reinterpret_cast<const uint16_t*>(prev) + lz_slot_index(g, t.own, 0, t.c);
+      if constexpr (LL == 8) { const lva_u32x4 v = *LVA_GLOBAL(lva_u32x4, pp); own_lo = ((unsigned long long)v.y << 32) | v.x; own_hi = ((unsigned long long)v.w << 32) | v.z; }
+      else if constexpr (LL == 4) { const lva_u32x2 v = *LVA_GLOBAL(lva_u32x2, pp); own_lo = ((unsigned long long)v.y << 32) | v.x; }
+      else own_lo = *LVA_GLOBAL(uint32_t, pp);
     }
-    if (!lazy_output<LL, P, CLS>(g, x, sr, cur, mout, s_slot, t.k, t.own, t.sc, y, crow, ownslot, asrc, rej0, lc, s_q, &s_qn)) why = 4;
+    if (!lazy_output<LL, P, CLS>(g, x, sr, cur, mout, reinterpret_cast<const uint16_t*>(s_ptrw), t.k, t.own, t.sc, y, crow, own_lo, own_hi, asrc, rej0,
+                                 lc, s_q, &s_qn, lz_spare_delta(g, ss, pos))) why = 4;
   }
   auto to_work_list = [&](int reason, uint32_t k, uint32_t c) __attribute__((always_inline)) {
     atomicAdd(&hdr->reason[reason - 1], 1ull);
@@ -1787,7 +1813,7 @@ __global__ __launch_bounds__(256) void lva_step_fixup_lazy(StepArgs args, Geomet
         cs = u2f(v.x); cy = i != 0 ? v.y ^ tg.fpc : v.y;
         const bool msg_row = i == 0 ? sr.stay_msg != 0 : sr.move_msg != 0;
         uint32_t p = lz_synth(j, kk, i == 0 ? sr.stay_kind : sr.move_kind);
-        if (!msg_row) p = lz_unpack(prev[lz_slot_index(g, lst, j, cv)] & 0xFFFFu);
+        if (!msg_row) p = lz_unpack(reinterpret_cast<const uint16_t*>(prev)[lz_slot_index(g, lst, j, cv)]);
         cb = i == 0 ? p : lz_move(p, ymove, x.lz);
       }
     }
@@ -1885,51 +1911,21 @@ __global__ __launch_bounds__(256) void lva_step_fixup_lazy(StepArgs args, Geomet
           for (int u = 0; u < 2 * P; ++u) wv2 = w == (uint32_t)u ? mw[u] : wv2;
         }
         if (e < l && w < Wd) mout[tg.own + e * sBlk + 2 * g.N + msg_word_off(g.N, tg.c, w, tg.np_dst)] = wv2;
-        if (e < l && w == 0) cur[lz_slot_index(g, tg.own, e, tg.c)] = lz_tag((li << 3) | lj, 0u) << 16;   // (tag: origin only)
-      } else if (e < l && w == 0) {
-        cur[lz_slot_index(g, tg.own, e, tg.c)] = lz_pack(p1) | (lz_tag((li << 3) | lj, 0u) << 16);
+      } else {
+        if (e < l && w == 0) reinterpret_cast<uint16_t*>(cur)[lz_slot_index(g, tg.own, e, tg.c)] = (uint16_t)lz_pack(p1);
+        const uint32_t spare = lz_spare_delta(g, ss, pos);   // the row a later step reads stale: its messages to the spare rows
+        if (spare) {
+          uint32_t wv2 = 0;
+          if (e < l) {
+            uint32_t mw[2 * P];
+            lz_message<P>(x, p1, empty, mw);
+#pragma unroll
+            for (int u = 0; u < 2 * P; ++u) wv2 = w == (uint32_t)u ? mw[u] : wv2;
+          }
+          if (e < l && w < Wd) cur[tg.own + spare + e * sBlk + 2 * g.N + msg_word_off(g.N, tg.c, w, tg.np_dst)] = wv2;
+        }
       }
     }
-  }
-}
-
-// Lazy mode, after a step between anchors: the row the host marked (SlotStep.flags, one per slot at most) will be read
-// STALE by a later step, whose entries could not compose pointers of another generation -- so the row's messages are
-// resolved now and stored in the spare row  R + pos % RS  of the buffer the step wrote; readers of the stale row start fresh
-// pointers there.  grid: x = groups of 64 conv states, y = half of the 8 lists, z = slot; thread = (list, conv state).
-template <int P>
-__global__ __launch_bounds__(256) void lva_lazy_spare_rows(StepArgs args, Geometry g, const DevCode* __restrict__ codes,
-                                                           uint32_t* __restrict__ trellis) {
-  SlotStep ss;
-  if (!load_slot(args, blockIdx.z, &ss)) return;
-  const uint32_t mat = (ss.flags >> kLzMatShift) & 3u;
-  if (!mat || lz_class(g, ss.t) == 0) return;
-  const uint32_t pos = ss.lo + mat - 1u;
-  if (pos >= ss.hi) return;
-  const DevCode& cd = codes[ss.orient];
-  const uint32_t c = blockIdx.x * 64 + (threadIdx.x & 63u), lst = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (c >= cd.nconv) return;
-  const uint32_t cm = compact_pos(cd, g, pos);
-  if (cm && lst >= 4) return;
-  if ((c & cd.vmask[pos]) != cd.vval[pos]) return;                    // :700
-  if (pos > 0) {                                                       // is list `lst` of this conv state stored?
-    const uint32_t pk = LVA_GLOBAL(uint16_t, cd.predtab[cd.ptype[pos]])[c];
-    const uint32_t has = ((pk >> 3) & 1u) | (((pk >> 7) & 1u) << 1) | (((pk >> 11) & 1u) << 2) | (((pk >> 15) & 1u) << 3);
-    if (cm ? has == 0 : !((has >> (lst & 3u)) & 1u)) return;
-  }
-  uint32_t* slot_base = trellis + (uint64_t)ss.slot * g.sSlot;
-  uint32_t* cur = slot_base + (uint64_t)((ss.t + 1) & 1u) * g.sPar;
-  const uint32_t own = (uint32_t)(((uint64_t)(pos % g.R) * 8 + lst) * g.sCrf);
-  const uint32_t spare = (uint32_t)(((uint64_t)(g.R + pos % g.RS) * 8 + lst) * g.sCrf);
-  LzCtx x;
-  lz_ctx(cd, g, slot_base, pos, c, &x);
-  const uint32_t* pp = cur + lz_slot_index(g, own, 0, c);
-  const uint32_t np_dst = cd.npair[pos];
-  for (uint32_t l = 0; l < g.L; ++l) {
-    if (cur[own + l * g.sBlk + 2 * c] == kNegInfBits) break;          // (:799: the unused tail of a list)
-    uint32_t mw[2 * P];
-    lz_message<P>(x, lz_unpack(pp[l] & 0xFFFFu), false, mw);
-    store_msg<P>(cur + spare + l * g.sBlk + 2 * g.N, g.N, c, np_dst, mw);
   }
 }
 
@@ -2628,7 +2624,7 @@ __global__ void lva_gather_final(Geometry g, const DevCode* __restrict__ codes, 
             for (uint32_t f = 2; f < g.F; ++f) w[f] = msg_word(g, mb, own + l * g.sBlk, c, f - 2, cd.npair[pos]);
           } else {                               // the entry's pointer names the stored message it descends from
             uint32_t mw[8];
-            lz_message<4>(x, lz_unpack(buf[lz_slot_index(g, own, l, c)] & 0xFFFFu), false, mw);
+            lz_message<4>(x, lz_unpack(reinterpret_cast<const uint16_t*>(buf)[lz_slot_index(g, own, l, c)]), false, mw);
             for (uint32_t f = 2; f < g.F; ++f) w[f] = mw[f - 2];
           }
         }
@@ -2757,16 +2753,6 @@ int launch_step_fast(const StepArgs& a, const Geometry& g, const DevCode* codes,
       case 2: hipLaunchKernelGGL((lva_step_fixup_lazy<2>), dim3(kFixGrid), dim3(256), 0, st, a, g, codes, trellis, hdr, items); break;
       case 3: hipLaunchKernelGGL((lva_step_fixup_lazy<3>), dim3(kFixGrid), dim3(256), 0, st, a, g, codes, trellis, hdr, items); break;
       default: hipLaunchKernelGGL((lva_step_fixup_lazy<4>), dim3(kFixGrid), dim3(256), 0, st, a, g, codes, trellis, hdr, items); break;
-    }
-    e = (int)hipGetLastError();
-    if (e || cls == 0) return e;
-    // the row a later step will read stale (one per slot at most; most launches: a few slots): its messages to the spare rows
-    dim3 sgrid(g.N / 64, 2, a.nslots);
-    switch (g.P) {
-      case 1: hipLaunchKernelGGL((lva_lazy_spare_rows<1>), sgrid, dim3(256), 0, st, a, g, codes, trellis); break;
-      case 2: hipLaunchKernelGGL((lva_lazy_spare_rows<2>), sgrid, dim3(256), 0, st, a, g, codes, trellis); break;
-      case 3: hipLaunchKernelGGL((lva_lazy_spare_rows<3>), sgrid, dim3(256), 0, st, a, g, codes, trellis); break;
-      default: hipLaunchKernelGGL((lva_lazy_spare_rows<4>), sgrid, dim3(256), 0, st, a, g, codes, trellis); break;
     }
     return (int)hipGetLastError();
   }

@@ -34,10 +34,10 @@ def _meta(asm):
 def test_register_and_lds_budgets(asm):
     meta = _meta(asm)
     pick = lambda pat: {k: v for k, v in meta.items() if re.search(pat, k)}
-    lazy = pick(r"lva_step_lazyILi8ELi3ELi[012]E")                 # the benchmark's three instances: four 512-thread workgroups per CU
-    assert len(lazy) == 3                                          # (160 KB of LDS per CU: 40 KB each, to the byte)
+    lazy = pick(r"lva_step_lazyILi8ELi3ELi[012]E")                 # the benchmark's three instances: three 512-thread workgroups per CU
+    assert len(lazy) == 3                                          # (32 KB of list heads + 8 KB of pointers + the queue of unproven matches)
     for k, v in lazy.items():
-        assert v["vgpr"] <= 64 and v["lds"] <= 40 * 1024 and v["scratch"] <= 48, (k, v)
+        assert v["vgpr"] <= 80 and v["lds"] <= 53 * 1024 and v["scratch"] == 0, (k, v)
     rec = pick(r"lva_step_big_recILi64E")                          # configs[4]: three 256-thread workgroups per CU
     assert len(rec) == 1
     for k, v in rec.items():
@@ -58,17 +58,3 @@ def test_big_list_output_phase_requests_a_round_at_once(asm):
         run = run + 1 if ln.startswith("global_load") else 0
         best = max(best, run)
     assert best >= 8, best          # four entries x (16 + 16 bytes) at three message planes
-
-
-def test_lazy_merge_loop_touches_no_scratch_memory(asm):
-    """the lazy instances spill a few values AROUND the merge (target description, used again in the output phase); inside the
-    merge loop -- the code between the first and the last posterior fetch (ds_bpermute) of an instance -- nothing may be spilled"""
-    for cls in (0, 1, 2):
-        m = re.search(r"^(_ZN3lva13lva_step_lazyILi8ELi3ELi%dE\S*):" % cls, asm, re.M)
-        body = asm[m.start():asm.index(".Lfunc_end", m.start())].split("\n")
-        perm = [i for i, ln in enumerate(body) if "ds_bpermute_b32" in ln]
-        assert len(perm) >= 4, (cls, len(perm))
-        # the two merges (flip: 8 lists, flop: 2 lists) each start with their list heads' posteriors and end with the loop's fetch
-        inside = [ln for ln in body[perm[0]:perm[-1]] if "scratch_" in ln]
-        heads = [ln for ln in inside if "scratch_store" in ln]
-        assert len(inside) - len(heads) <= 2 and len(heads) <= 2, (cls, inside)      # (one spill between the flip and the flop merge)
