@@ -337,15 +337,15 @@ def main():
         dom_ms = acc["dom_ms"] if use_events else acc["span_ms"]
         achieved = (acc["alg"] / 1e9) / (dom_ms / 1e3) if dom_ms > 0 else 0.0
         kname = {2: "lva_step_fast<%d,P>" % a.list_size if a.list_size in (2, 4, 8) else ("lva_step_acs<P>" if a.list_size == 1 else "lva_step_big<LL,P> / lva_step_big_rec<LL>"),
-                 4: "lva_step_lazy<%d,P,0> | <%d,P,1> | <%d,P,2> (anchor step every fourth launch -- messages stored --, the step after it, "
-                    "the other two: the slots are phase-aligned, so a launch runs ONE instance over all slots; avg_launch_ms is the "
-                    "mean over all launches)" % (a.list_size, a.list_size, a.list_size),
+                 4: "lva_step_lazy<%d,P,true> | lva_step_lazy<%d,P,false> (the anchor-step and the odd-step instance: the slots are "
+                    "phase-aligned, so even launches run the first over all slots and odd launches the second; avg_launch_ms is the "
+                    "mean over both kinds of launch)" % (a.list_size, a.list_size),
                  3: "lva_step_wave", 1: "lva_step_exact"}.get(prof["kernel"], "?")
         # HBM bytes per launch from this round's PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
         # passes, scripts/pmc_mem.sh), per read-step, scaled to this run's mean number of active slots per launch
         traffic, tsrc, limiter = None, None, None
         try:
-            for name in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+            for name in ("r6_traffic.json", "r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
                 pth = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(pth):
                     tj = json.load(open(pth))

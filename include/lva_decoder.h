@@ -54,7 +54,7 @@ typedef struct lva_config {
                                1 = exact kernel, one thread per target; 2 = fast kernel + exact fix-up (L = 1, 2, 4, 8:
                                lva_step_fast / lva_step_acs; any other 2 <= L <= 64: lva_step_big); 3 = exact kernel, one
                                wavefront per target (2 <= L <= 64); 4 = fast kernel with lazy messages (L = 2, 4, 8:
-                               messages materialised every fourth (m = 6: second) time step, 16-bit pointers in between, lva_step_lazy).  Every mode gives the
+                               messages materialised every second time step, lva_step_lazy).  Every mode gives the
                                reference's lists bit for bit on every input the reference decodes: targets the fast
                                kernels cannot decide (score ties, non-finite sums, fingerprint collisions) go through a
                                work list to an exact pass, and when that list overflows (tie-dense posteriors: quantised
@@ -129,16 +129,6 @@ int lva_code_tables(int32_t mem_conv, int32_t rate, uint32_t msg_len, int32_t rc
 int lva_band_table(int32_t mem_conv, int32_t rate, uint32_t msg_len, int32_t rc, const char *sync_marker,
                    uint32_t sync_period, uint32_t nblk, uint32_t max_deviation, uint32_t *reference_lo_hi,
                    uint32_t *working_lo_hi);
-
-/* Kernel mode 4 ("lazy messages"), for inspection/tests: the band table of a read of nblk blocks as the kernels read it --
- * words[t] = lo | hi << 10 | flags << 20 (working band; flag bits: csrc/lva_device.h kLz*: the row below the band is read stale
- * and where its messages live; which row of the step is copied to the spare rows because a later step reads it stale) -- for
- * an anchor step every anchor_period (2 or 4) steps, and the ring / spare positions a decoder with this max_deviation keeps
- * per parity buffer.  words may be NULL.  Returns LVA_ERR_UNSUPPORTED if the band breaks an assumption of the scheme (never
- * for a band this library computes; tests/test_host_logic.py simulates the scheme on these words). */
-int lva_lazy_band_words(int32_t mem_conv, int32_t rate, uint32_t msg_len, int32_t rc, const char *sync_marker,
-                        uint32_t sync_period, uint32_t nblk, uint32_t max_deviation, uint32_t anchor_period,
-                        uint32_t *words, uint32_t *ring_positions, uint32_t *spare_positions);
 
 /* `-m encode` (:215-225): conv_encode (:450-499) + 2-bit base packing (:540-551).
  * msgs: n_msgs*msg_len bytes of 0/1.  out_bases: n_msgs*oligo_len bytes, values 0..3 = A,C,G,T. */

@@ -17,7 +17,7 @@ ERRORS = {
 
 # every symbol include/lva_decoder.h declares
 EXPORTS = [
-    "lva_version", "lva_abi_version", "lva_strerror", "lva_last_hip_error", "lva_code_describe", "lva_code_tables", "lva_band_table", "lva_lazy_band_words",
+    "lva_version", "lva_abi_version", "lva_strerror", "lva_last_hip_error", "lva_code_describe", "lva_code_tables", "lva_band_table",
     "lva_encode", "lva_algorithmic_bytes", "lva_decoder_create", "lva_decoder_destroy",
     "lva_decode_batch", "lva_decode_batch_device", "lva_decoder_profile", "lva_decoder_set_launch_events", "lva_device_alloc",
     "lva_device_free", "lva_device_upload", "lva_device_synchronize",
@@ -110,8 +110,6 @@ def load_library():
     L.lva_code_describe.argtypes = [i32, i32, u32, i32, cp, u32, ctypes.POINTER(CodeInfoStruct)]
     L.lva_code_tables.argtypes = [i32, i32, u32, i32, cp, u32, vp, vp, vp, vp, vp]
     L.lva_band_table.argtypes = [i32, i32, u32, i32, cp, u32, u32, u32, vp, vp]
-    if hasattr(L, "lva_lazy_band_words") or not os.environ.get("LVA_LIB_PATH"):       # (LVA_LIB_PATH: an older build in a head-to-head run)
-        L.lva_lazy_band_words.argtypes = [i32, i32, u32, i32, cp, u32, u32, u32, u32, vp, vp, vp]
     L.lva_encode.argtypes = [i32, i32, u32, vp, i32, vp]
     L.lva_algorithmic_bytes.argtypes = [i32, i32, u32, i32, cp, u32, u32, u32, u32, ctypes.POINTER(ctypes.c_double)]
     L.lva_decoder_create.argtypes = [ctypes.POINTER(Config), ctypes.POINTER(vp)]

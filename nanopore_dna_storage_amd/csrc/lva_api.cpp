@@ -176,20 +176,6 @@ int lva_band_table(int32_t mem_conv, int32_t rate, uint32_t msg_len, int32_t rc,
   return LVA_OK;
 }
 
-int lva_lazy_band_words(int32_t mem_conv, int32_t rate, uint32_t msg_len, int32_t rc, const char* sync_marker, uint32_t sync_period,
-                        uint32_t nblk, uint32_t max_deviation, uint32_t anchor_period, uint32_t* words, uint32_t* ring_positions,
-                        uint32_t* spare_positions) {
-  if (anchor_period != 2 && anchor_period != 4) return LVA_ERR_ARG;
-  Code c;
-  const int st = build_code(&c, mem_conv, rate, msg_len, rc, sync_marker, sync_period);
-  if (st != LVA_OK) return st;
-  if (max_deviation == LVA_MAX_DEVIATION_DEFAULT) max_deviation = msg_len + (uint32_t)mem_conv + 1;
-  if (ring_positions) *ring_positions = (uint32_t)std::min<uint64_t>(c.npos, lazy_ring(max_deviation, anchor_period));
-  if (spare_positions) *spare_positions = lazy_spare(anchor_period);
-  if (words && !c.band_words(nblk, max_deviation, anchor_period, words)) return LVA_ERR_UNSUPPORTED;
-  return LVA_OK;
-}
-
 int lva_algorithmic_bytes(int32_t mem_conv, int32_t rate, uint32_t msg_len, int32_t rc, const char* sync_marker,
                           uint32_t sync_period, uint32_t nblk, uint32_t list_size, uint32_t max_deviation,
                           double* out) {
@@ -234,14 +220,7 @@ static int upload_codes(lva_decoder* d) {
       r.np2 = p >= 2 ? dc[o].npair[p - 2] : 1u;
       auto one_bit = [&](int64_t at) -> uint32_t { return at >= 1 && dc[o].ptype[at] == 0 ? 1u : 0u; };   // compact lists there (Geometry::cmp)
       r.cmp3 = one_bit(p) | one_bit((int64_t)p - 1) << 1 | one_bit((int64_t)p - 2) << 2;
-      // lazy pointers: per position pos-e -- the step into it shifts in two bits, it stores compact lists, planes in use there
-      r.lz = 0;
-      for (int64_t e = 0; e < 8; ++e) {
-        const int64_t at = (int64_t)p - e;
-        if (at >= 1 && dc[o].ptype[at] != 0) r.lz |= 1u << e;
-        r.lz |= one_bit(at) << (8 + e);
-        if (e < 5) r.lz |= (uint32_t)(at >= 0 ? dc[o].npair[at] : 1u) << (16 + 3 * e);
-      }
+      r.pad1 = 0;
       r.pred = dc[o].predtab[dc[o].ptype[p] & 3]; r.pred1 = dc[o].predtab[dc[o].ptype[q] & 3];
     }
   }
@@ -313,16 +292,7 @@ int lva_decoder_create(const lva_config* cfg, lva_decoder** out) {
   const bool lazy_ok = (cfg->list_size == 2 || cfg->list_size == 4 || cfg->list_size == 8) && c.nconv >= 64;
   if (cfg->kernel == 4 && !lazy_ok) { delete d; return LVA_ERR_UNSUPPORTED; }
   const bool lazy = cfg->kernel == 4 || (cfg->kernel == 0 && lazy_ok);
-  // anchor period K: 4 where the 2 (K - 1) register bits a pointer may have to carry fit its 6-bit field AND an anchor's shift of
-  // up to 2 K message bits stays within the conv register they are read back from (m >= 8); 2 otherwise.
-  // LVA_LAZY_K (honoured with LVA_TESTING=1 only): force 2 or 4 where both are possible (measurements, tests)
-  uint32_t lazyK = lazy ? (c.mem_conv >= 8 ? 4u : 2u) : 0u;
-  if (lazy) {
-    const char* kenv = std::getenv("LVA_LAZY_K");
-    const char* testing = std::getenv("LVA_TESTING");
-    if (kenv && testing && testing[0] == '1' && std::atoi(kenv) == 2) lazyK = 2;
-  }
-  const uint64_t ring = std::min<uint64_t>(c.npos, lazy ? (uint64_t)lazy_ring(d->max_dev, lazyK) : 2ull * d->max_dev + 1);
+  const uint64_t ring = std::min<uint64_t>(c.npos, 2ull * d->max_dev + (lazy ? 2 : 1));
   // the big-list kernel (kernel mode 2 at list sizes without a small-list instance) keeps its lists in the record layout
   // where the message has three planes and L is a multiple of 4 (Geometry::rec)
   const bool small = cfg->list_size == 1 || cfg->list_size == 2 || cfg->list_size == 4 || cfg->list_size == 8;
@@ -330,8 +300,8 @@ int lva_decoder_create(const lva_config* cfg, lva_decoder** out) {
   // compact lists at one-bit positions (Geometry::cmp): the lazy kernels, the L = 1 kernel (lva_step_acs) and the big-list kernel on
   // the plane layout (make_geometry drops the flag where the record layout applies)
   const bool acs = cfg->list_size == 1 && (cfg->kernel == 0 || cfg->kernel == 2) && c.nconv >= 64;
-  d->g = make_geometry(c.nconv, cfg->list_size, c.msg_bits(), (uint32_t)std::max<uint64_t>(ring, 1), lazyK, big ? 1u : 0u,
-                       (acs || big) ? 1u : 0u, lazy ? lazy_spare(lazyK) : 0u);
+  d->g = make_geometry(c.nconv, cfg->list_size, c.msg_bits(), (uint32_t)std::max<uint64_t>(ring, 1), lazy ? 1u : 0u, big ? 1u : 0u,
+                       (acs || big) ? 1u : 0u);
   if (d->g.sPar >= ((uint64_t)1 << 32)) { delete d; return LVA_ERR_TOO_MANY_STATES; }
 
   int ndev = 0;
@@ -498,7 +468,25 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
       band_at[(size_t)r] = at;
       const Code& c = d->code[rc_flags && rc_flags[r] ? 1 : 0];
       const uint32_t nb = (uint32_t)len[r];
-      if (!c.band_words(nb, d->max_dev, d->g.lazy, band.data() + at)) return LVA_ERR_UNSUPPORTED;   // (cannot happen: tests/test_host_logic.py)
+      // lazy mode: when was each position's row of either parity buffer last written?  Step t reads the buffer written
+      // by steps of t-1's parity; only the row of position lo-1 can be older than t-1 ("stale"), and at odd t
+      // its entries' messages live in the message buffer of the (even) step that wrote it
+      std::vector<int64_t> last_w[2];
+      if (d->g.lazy) { last_w[0].assign(c.npos + 1, -1); last_w[1].assign(c.npos + 1, -1); if (c.npos) last_w[1][0] = -1; }
+      for (uint32_t t = 0; t < nb; ++t) {
+        uint32_t lo, hi;
+        working_band(c, t, nb, d->max_dev, &lo, &hi);
+        uint32_t w = lo | (hi << 16);
+        if (d->g.lazy) {
+          const int pc = (int)((t + 1) & 1u);                // parity class of the steps that wrote step t's "prev" buffer: t-1
+          if (t >= 1 && lo >= 1) {
+            const int64_t lw = last_w[pc][lo - 1];
+            if (lw >= 0 && lw != (int64_t)t - 1) w |= 1u << 30 | (uint32_t)((lw >> 1) & 1) << 31;
+          }
+          for (uint32_t p = lo; p < hi; ++p) last_w[t & 1u][p] = t;
+        }
+        band[at + t] = w;
+      }
       at += nb;
     }
   }
@@ -557,10 +545,10 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
       sd.post = post_dev + (size_t)beg[r] * 40;
       sd.band = d->d_band + band_at[(size_t)r];
       sd.nblk = (uint32_t)len[r]; sd.orient = rc_flags && rc_flags[r] ? 1u : 0u;
-      // Lazy mode: every read starts on a launch that is a MULTIPLE OF K (a read that arrives in between idles for up to K - 1
-      // launches: 1 in ~500), so all slots are at the same kind of step (anchor, first after, other) on every launch -- a launch
-      // then runs ONE instance of lva_step_lazy over a grid without workgroups of the wrong kind (launch_step_fast)
-      sd.start = d->kernel == 4 ? (d->launch_no + d->g.lazy - 1u) / d->g.lazy * d->g.lazy : d->launch_no; sd.pad = 0;
+      // Lazy mode: every read starts on an EVEN launch (a read that arrives on an odd one idles for one launch: 1 in ~500),
+      // so all slots are at an even time step on even launches and at an odd one on odd launches -- a launch then runs ONE
+      // instance of lva_step_lazy over a grid without workgroups of the wrong kind (launch_step_fast, phase_aligned)
+      sd.start = d->launch_no + (d->kernel == 4 ? (d->launch_no & 1u) : 0u); sd.pad = 0;
       slot[s].read = r; slot[s].end = sd.start + sd.nblk;
       if (sd.start != d->launch_no) ++waiting;
       ib.slot[ib.n] = (uint32_t)s; ib.desc[ib.n] = sd;
@@ -610,7 +598,7 @@ static int decode_impl(lva_decoder* d, const float* post_dev, const int64_t* beg
       const int32_t r = slot[s].read;
       const uint32_t nb = (uint32_t)len[r], orient = rc_flags && rc_flags[r] ? 1u : 0u;
       const uint32_t last = band[band_at[(size_t)r] + nb - 1];
-      if ((last & kBandPosMask) <= npos - 1 && npos - 1 < ((last >> kBandHiShift) & kBandPosMask)) {   // otherwise the final state was never written: empty list
+      if ((last & 0xFFFFu) <= npos - 1 && npos - 1 < ((last >> 16) & 0x3FFFu)) {   // otherwise the final state was never written: empty list
         gb.a[gb.n] = GatherArgs{(uint32_t)s, (uint32_t)(nb & 1u), orient, (uint32_t)r, nb};
         if (++gb.n == (uint32_t)kTurnoverBatch) { const int st = flush_gathers(); if (st) return st; }
         gathered[(size_t)r] = 1;

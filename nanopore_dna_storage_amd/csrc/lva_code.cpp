@@ -240,45 +240,6 @@ void Code::working_band(uint32_t t, uint32_t nblk, uint32_t max_dev, uint32_t* l
   *lo_out = lo; *hi_out = hi;
 }
 
-bool Code::band_words(uint32_t nblk, uint32_t max_dev, uint32_t K, uint32_t* words) const {
-  // flag layout: lva_device.h (kBandHiShift = 10, kBandFlagShift = 20; kLzStale = 1, kind << 1, row to copy << 3)
-  std::vector<int64_t> last_w[2];        // by parity of the writing step: when was the row of position p last written?
-  std::vector<uint32_t> lo_of(nblk, 0);
-  if (K) { last_w[0].assign(npos + 1, -1); last_w[1].assign(npos + 1, -1); }
-  bool ok = true;
-  for (uint32_t t = 0; t < nblk; ++t) {
-    uint32_t lo, hi;
-    working_band(t, nblk, max_dev, &lo, &hi);
-    lo_of[t] = lo;
-    uint32_t w = lo | (hi << 10);
-    if (K) {
-      // Step t reads the buffer written by steps of t-1's parity; only the row of position lo-1 can be older than t-1
-      // ("stale", SURVEY 8a8: the reference never clears its buffers).  Its entries carry messages of their own: in message
-      // buffer (lw / K) & 1 when an anchor step lw wrote it, in the spare rows otherwise -- copied there right after step lw,
-      // which is told so here.
-      if (t >= 1 && lo >= 1 && hi > lo) {
-        const int64_t lw = last_w[(t - 1) & 1u][lo - 1];
-        if (lw >= 0 && lw != (int64_t)t - 1) {
-          uint32_t kind;
-          if (lw % K == 0) kind = (uint32_t)(lw / K) & 1u;
-          else {
-            kind = 2u;
-            const uint32_t row = lo - 1 - lo_of[(size_t)lw] + 1;        // 1: the lowest row of step lw, 2: the next
-            const uint32_t had = (words[lw] >> 23) & 3u;
-            if (row < 1 || row > 3 || (had && had != row)) ok = false;
-            else words[lw] |= row << 23;
-          }
-          w |= (1u | (kind << 1)) << 20;
-        }
-      }
-      for (uint32_t p = lo; p < hi; ++p) last_w[t & 1u][p] = t;
-      if (t >= 1 && lo > lo_of[t - 1] + 1) ok = false;                   // (the band advances one position per step at most)
-    }
-    words[t] = w;
-  }
-  return ok;
-}
-
 static double band_bytes(const Code& c, uint32_t nblk, uint32_t list_size, uint32_t max_dev, bool working) {
   const double entry = 4.0 + 4.0 * c.msg_words();
   std::vector<uint64_t> prefix(c.npos + 1, 0);

@@ -61,16 +61,7 @@ struct Code {
   // the positions that cannot reach the final one any more): what bench.py calls `frac_moved`
   double working_bytes(uint32_t nblk, uint32_t list_size, uint32_t max_dev) const;
   void working_band(uint32_t t, uint32_t nblk, uint32_t max_dev, uint32_t* lo, uint32_t* hi) const;
-  // The band table of a read as the kernels read it: words[t] = lo | hi << 10 | flags << 20 (working band of step t).
-  // K = 0: no flags.  K = 2 or 4: lazy mode with an anchor step every K steps (lva_kernels.hip "lazy messages"; flag bits:
-  // lva_device.h kLz*) -- which steps read the row below their band stale and where its messages are, and which row of a step
-  // must have its messages copied to the spare rows because a later step will read it stale.  Returns false when the band
-  // breaks an assumption of the scheme (never for bands of Code::working_band; the caller refuses the read's lazy decode).
-  bool band_words(uint32_t nblk, uint32_t max_dev, uint32_t K, uint32_t* words) const;
 };
-// ring positions of a parity buffer in lazy mode, and spare positions behind them (Geometry::R, Geometry::RS)
-inline uint32_t lazy_ring(uint32_t max_dev, uint32_t K) { return 2u * max_dev + K; }
-inline uint32_t lazy_spare(uint32_t K) { return K + 2u; }
 
 // set_conv_params (:264-415).  Returns 0 or a negative LVA_ERR_* code (include/lva_decoder.h).
 int build_code(Code* c, int mem_conv, int rate, uint32_t msg_len, int rc, const char* sync_marker,

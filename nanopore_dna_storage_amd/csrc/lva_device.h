@@ -26,7 +26,7 @@
 //     (< npos - nblk + t): the host clips the band table of every step to that range
 //     (lva_api.cpp decode_impl), and "outside the band" already reads as -inf / is never used.
 //   * variants of this layout, selected per decoder (Geometry below): compact lists at one-bit
-//     positions (cmp: 4 lists per ring position there), 16-bit message pointers behind every list
+//     positions (cmp: 4 lists per ring position there), back-pointer bytes behind every list
 //     (lazy), and [conv][entry] records instead of planes for long lists (rec).
 //
 // Message fingerprint: XOR over the set message bits of a fixed pseudo-random 32-bit word per
@@ -51,10 +51,7 @@ struct PosRec {                  // everything a workgroup needs to know about t
   const uint16_t* pred1;         // predtab[ptype[pos-1]]
   uint32_t cmp3;                 // compact-list flags (Geometry::cmp): bit 0 = position pos, bit 1 = pos-1, bit 2 = pos-2 is a one-bit
                                  // position >= 1 (its lists are stored four per conv state)
-  uint32_t lz;                   // lazy pointers (lva_kernels.hip "lazy messages"), facts about positions pos-e, e = 0..7:
-                                 //   bits 0-7   bit e: the step into pos-e shifts in TWO message bits (pos-e >= 1 and block type != 0)
-                                 //   bits 8-15  bit e: pos-e stores compact lists (a one-bit position >= 1)
-                                 //   bits 16-30 three bits per e = 0..4: message planes in use at pos-e
+  uint32_t pad1;
 };
 static_assert(sizeof(PosRec) == 64, "PosRec is one 64-byte scalar load");
 
@@ -74,7 +71,7 @@ struct DevCode {                 // one per orientation (0 = forward, 1 = revers
 // whole schedule of a batch without per-launch argument tables, for any number of slots.
 struct SlotDesc {
   const float* post;             // block 0 of the read's posterior matrix (device)
-  const uint32_t* band;          // [nblk] lo | hi << 10 (| lazy-mode flags << 20, kBandFlag*): the band of every time step (:677-679),
+  const uint32_t* band;          // [nblk] lo | hi << 16 (| lazy-mode flags << 30): the band of every time step (:677-679),
                                  // evaluated on the host exactly as the reference binary does (Code::band)
   uint32_t nblk, orient;
   uint32_t start;                // launch number of the read's time step 0
@@ -89,20 +86,14 @@ struct SlotStep {                // what one read slot does in one trellis-step 
   uint32_t lo, hi;               // band of step t
   uint32_t prev_hi;              // band end of step t-1 (1 at t = 0: only position 0 is initialised)
   uint32_t orient;
-  uint32_t flags;                // lazy mode (kernel 4), kLz* below: bit 0 = the row of position lo-1 in the previous buffer is stale
-                                 // (written before step t-1); bits 1-2 = where the messages of its entries live (message buffer 0 / 1,
-                                 // or 2 = the spare rows of the previous buffer); bits 3-4 = the row of this step (1: lo, 2: lo+1,
-                                 // 3: lo+2) that a later step will read stale: its messages are copied to the spare rows after the step
+  uint32_t flags;                // lazy mode (kernel 4): bit 0 = the row of position lo-1 in the previous buffer is stale (written
+                                 // before step t-1); bit 1 = which message buffer the messages of its entries live in
   uint32_t pad;
   uint32_t srccmp[2];            // Geometry::cmp: bit y = the SOURCE position lo + y - 1 of band position lo + y stores compact lists
                                  // (a workgroup then stages 4 x L rows instead of 8 x L) -- known from the slot record alone, before
                                  // anything else is loaded; band positions beyond 64 read the flag from the position record
 };
 static_assert(sizeof(SlotStep) == 48, "twelve words");
-
-// band table word: lo | hi << 10 | flags << 20 (positions <= 256: DevCode's tables)
-constexpr uint32_t kBandHiShift = 10, kBandPosMask = 0x3FFu, kBandFlagShift = 20;
-constexpr uint32_t kLzStale = 1u, kLzKindShift = 1, kLzMatShift = 3;
 
 struct StepArgs {
   const SlotDesc* slots;         // device
@@ -124,10 +115,7 @@ struct StepArgs {
 struct Geometry {                // strides in 32-bit words
   uint32_t N, L, W, F, R, P;
   uint32_t sBlk;                 // one (ring, crf, list entry) block = N*F
-  uint32_t lazy;                 // kernel mode 4: messages are materialised every K-th time step ("anchor" steps), 16-bit pointers to the
-                                 // last stored message in between (lva_kernels.hip, "lazy messages"); K = lazy (2 or 4), 0 = off
-  uint32_t RS;                   // lazy mode: spare ring positions behind the R ring positions of either parity buffer; the message planes
-                                 // of spare row  R + pos % RS  hold the messages of a row that later steps read stale
+  uint32_t lazy;                 // kernel mode 4: messages are materialised every second time step (lva_kernels.hip, "lazy")
   uint32_t cmp;                  // compact lists (every plane-layout fast kernel: lazy mode, the L = 1 kernel, the big-list kernel): at a one-bit position >= 1 a conv state has two COMPLEMENTARY bases
                                  // ({A,T} or {C,G}: its two predecessors differ in the register bit the step shifts out, which both generators tap), so 4 of its 8 crf lists exist -- the list of
                                  // crf state k is stored as list k >> 1 of the ring position (flip {A|C}, flip {T|G}, flop {A|C}, flop {T|G}).
@@ -141,17 +129,16 @@ struct Geometry {                // strides in 32-bit words
   uint64_t sCrf, sRing, sPar, sSlot;
 };
 
-inline Geometry make_geometry(uint32_t N, uint32_t L, uint32_t msg_bits, uint32_t R, uint32_t lazy = 0, uint32_t rec = 0, uint32_t cmp = 0,
-                              uint32_t RS = 0) {
+inline Geometry make_geometry(uint32_t N, uint32_t L, uint32_t msg_bits, uint32_t R, uint32_t lazy = 0, uint32_t rec = 0, uint32_t cmp = 0) {
   Geometry g;
   g.N = N; g.L = L; g.P = (msg_bits + 63) / 64; if (g.P == 0) g.P = 1;
   g.W = 2 * g.P; g.F = g.W + 2; g.R = R;
-  g.lazy = lazy; g.RS = lazy ? RS : 0u; g.rec = (rec && !lazy && g.P == 3 && L >= 32 && L % 4 == 0) ? 1u : 0u;   // (below 32 entries the plane layout is faster: measured)
+  g.lazy = lazy; g.rec = (rec && !lazy && g.P == 3 && L >= 32 && L % 4 == 0) ? 1u : 0u;   // (below 32 entries the plane layout is faster: measured)
   g.cmp = ((lazy || cmp) && !g.rec) ? 1u : 0u;       // (the record layout keeps a list's entries together: a list that does not exist is a hole of whole lines)
   g.sBlk = N * g.F;
-  // lazy mode: behind the L entry blocks of a (ring, crf) list, L 16-bit pointers per conv state ([conv][entry])
-  g.sCrf = (uint64_t)g.sBlk * L + (lazy ? (uint64_t)N * L / 2 : 0); g.sRing = g.sCrf * 8;
-  g.sPar = g.sRing * (R + g.RS); g.sSlot = g.sPar * 2;
+  // lazy mode: behind the L entry blocks of a (ring, crf) list, L back-pointer bytes per conv state ([conv][entry])
+  g.sCrf = (uint64_t)g.sBlk * L + (lazy ? (uint64_t)N * L / 4 : 0); g.sRing = g.sCrf * 8;
+  g.sPar = g.sRing * R; g.sSlot = g.sPar * 2;
   return g;
 }
 
@@ -170,7 +157,7 @@ struct WorkHdr {
 // final-state gather: result record per read = [crf 8][list L][field F] words
 struct GatherArgs {
   uint32_t slot, parity, orient, read;
-  uint32_t nblk;                 // blocks of the read (lazy mode: whether the last step stored messages or pointers)
+  uint32_t nblk;                 // blocks of the read (lazy mode: whether the last step stored messages or back-pointers)
 };
 
 // Reads enter and leave their slots in batches: one launch serves every slot that turns over at this step (small trellises turn

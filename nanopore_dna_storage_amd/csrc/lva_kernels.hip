@@ -870,9 +870,9 @@ namespace {
 // Tuning constants, each the measured best of its experiment series (DESIGN_HISTORY.md; the rejected variants are kept as
 // diffs under scripts/experiments/, not as switches in this file).
 constexpr uint32_t TS = TS_TILE;         // source conv states per workgroup tile (workgroup = 8*TS threads); 32 measured 10 % slower
-constexpr int kLazyMinWaves = 6;         // the lazy instances: three 512-thread workgroups per CU (48 KB of LDS each), 80 registers
+constexpr int kLazyMinWaves = 8;         // both lazy instances held to 64 registers: four 512-thread workgroups per CU (the anchor
+                                         // instance's own count is 66: one 8-byte spill outside the merge loop, +1.6 % at m=11)
 constexpr uint32_t kFixupLazyGrid = 4096;   // workgroups (of four wavefronts) of lva_step_fixup_lazy
-constexpr uint32_t kLazyQueue = 640;    // unproven fingerprint matches a workgroup queues (more: compared in place)
 constexpr int kLazyInFlight = 2;         // anchor instance: entries whose message loads are in flight together (3: -3 %, 4: -12 %)
 
 
@@ -1278,372 +1278,254 @@ __global__ __launch_bounds__(8 * TS) void lva_step_fast(StepArgs args, Geometry 
 //
 // The reference carries the whole message with every list entry through every time step (:771-774).  Scores and
 // fingerprints decide everything the merge does; the message itself is only needed to confirm a fingerprint match and
-// at the very end.  So here the message is MATERIALISED EVERY K-th STEP (K = Geometry::lazy, 2 or 4): a step with
-// t % K == 0 ("anchor") stores messages as lva_step_fast does; every other step stores ONE 16-BIT POINTER per accepted
-// entry instead -- not to the entry's source one step ago (a chain an anchor would have to walk hop by hop), but straight
-// to the stored message the entry descends from:
-//     bits 0-2   index of that entry in its list            bits 6-7   d: positions the path has advanced since (0..3)
-//     bits 3-5   crf state of that list                     bits 8-13  the d moves' lost register bits ("ylow")
-//     bits 14-15 where: message buffer 0 / 1, or 2 | parity = the spare rows of that parity buffer
-//   A pointer is COMPOSED, not followed: a stay copies its source entry's pointer; a move adds one position and the one or
-//   two register bits the move shifted out.  From (target conv state c, d, ylow) the stored entry's conv state is
-//   ((c << S) | ylow) mod 2^m  (S = message bits of the d moves, from the position record), its position pos - d; its message,
-//   shifted by S with the S newest bits of c shifted in (the register's top bits ARE the newest message bits, newest first),
-//   is the entry's message.  So an anchor gathers ONE stored message per accepted entry however long ago the last anchor
-//   was, and steps in between move no messages at all.
-//   * Two pointers that are equal name the same stored message and the same shift: the messages are equal.  Practically
-//     every fingerprint match is of that kind (the same path through two orders of stay and move), so matches are confirmed
-//     by comparing two words; only pairs whose pointers differ are compared on the full messages (one gather each).
-//   * two message buffers (the message planes of the two parity buffers): anchor step t writes buffer (t / K) & 1 and reads,
-//     through the pointers, the other one -- never rows it writes;
-//   * the stale row (position lo-1 read with contents older than t-1): its entries' pointers are of another
-//     generation, so such a row always carries messages of its own -- either it was written by an anchor step, or the host,
-//     which knows the band of every step, had its messages copied to the spare rows of its parity buffer right after it was
-//     written (lva_lazy_spare_rows; one row per step at most).  Readers of a stale row start fresh pointers at its entries.
-//     Rows below the band are never overwritten, the ring has K more positions than the band is wide, and RS spare positions.
-//   * the exact path (lva_step_fixup_lazy, one wavefront per target) composes and resolves pointers the same way.
+// at the very end.  So here the message is MATERIALISED EVERY SECOND STEP: a step with even t ("anchor") stores messages
+// as lva_step_fast does; a step with odd t stores one byte per accepted entry instead -- where the entry came from in
+// step t-1's lists (list i, index j) and which message buffer holds that entry's message.  The next anchor step follows
+// two hops (its candidate -> step t-1's entry -> that entry's byte -> step t-2's entry), gathers the message there and
+// shifts in the bits of both moves.  Odd steps move no messages at all (except to confirm fingerprint matches): about a
+// quarter of the bytes of a step pair disappears.
+//   * two message buffers (the message planes of the two parity buffers, otherwise unused at odd steps): anchor step t
+//     writes buffer (t >> 1) & 1 and reads, through the bytes, whichever buffer the byte names -- never rows it writes;
+//   * the stale row (position lo-1 read with contents older than t-1) keeps working: its entries' messages
+//     are where they were written (rows below the band are never overwritten); the host tells odd steps which buffer
+//     that is (SlotStep.flags), anchor steps read it from the byte; two hops reach position lo-2, so the ring has one
+//     more position (R = 2 max_deviation + 2);
+//   * the exact path (lva_step_fixup_lazy, one wavefront per target) resolves messages the same way.
 // ---------------------------------------------------------------------------------------
 namespace {
 
-// register form of a pointer (one 32-bit word): bits 0-2 j, 3-5 kk, 14-15 kind, 16-18 d (an anchor composes one more move: <= 4),
-// 19-26 ylow (<= 8 bits there)
-constexpr uint32_t kLzHead = 0xC03Fu;
-__device__ __forceinline__ uint32_t lz_unpack(uint32_t st) { return (st & kLzHead) | (((st >> 6) & 3u) << 16) | (((st >> 8) & 0x3Fu) << 19); }
-__device__ __forceinline__ uint32_t lz_pack(uint32_t p) { return (p & kLzHead) | (((p >> 16) & 3u) << 6) | (((p >> 19) & 0x3Fu) << 8); }
-// a fresh pointer to entry j of the list of crf state kk of a row that carries messages
-__device__ __forceinline__ uint32_t lz_synth(uint32_t j, uint32_t kk, uint32_t kind) { return j | (kk << 3) | (kind << 14); }
-// message bits shifted in by the moves into positions pos-e0, pos-e0-1, .. (d of them): lz = PosRec::lz of pos
-__device__ __forceinline__ uint32_t lz_shift(uint32_t lz, uint32_t e0, uint32_t d) {
-  return d + (uint32_t)__builtin_popcount(((lz & 0xFFu) >> e0) & ((1u << d) - 1u));
-}
-// the pointer of an entry made by a move into pos from a source entry (at pos-1) whose pointer is p; y = the register bits the move lost
-__device__ __forceinline__ uint32_t lz_move(uint32_t p, uint32_t y, uint32_t lz) {
-  const uint32_t d = (p >> 16) & 7u;
-  return p + (1u << 16) + (y << (19u + lz_shift(lz, 1, d)));
-}
-
-struct LzCtx {                   // pointer arithmetic at one target (everything but c is uniform over the workgroup / wavefront)
-  const uint32_t* M0; const uint32_t* M1;   // the two parity buffers of the slot (their message planes = message buffers 0 and 1)
-  uint32_t N, sBlk, sCrf, pw, m, R, RS;
-  uint32_t lz, rp, rsp;          // PosRec::lz of the target's position, pos % R, pos % RS
-  uint32_t c;                    // target conv state
+struct LazyCtx {
+  const uint32_t* M0; const uint32_t* M1;   // the two parity buffers of the slot (message planes = message buffers 0 and 1)
+  const uint8_t* bp_prev;        // back-pointer bytes of the previous step's buffer (anchor steps)
+  uint32_t N, sBlk, sCrf, pw, m;
+  uint32_t c, cp, k, own, src, src2;   // target conv, source conv, target crf; word offsets of (ring(pos),k), ring(pos-1), ring(pos-2)
+  uint32_t sh_p, nb_p;           // the move into (pos, c)
+  uint32_t sh_q, nb_q, pk1;      // the move into (pos-1, cp); predecessors of cp there (predtab nibbles)
+  uint32_t np_p, np_p1, np_p2;   // message planes in use at pos, pos-1, pos-2
+  uint32_t t, fb, stale_pos1, stale_mb;  // time step; message buffer of fresh step t-1 entries; sources at pos-1 stale? its buffer
+  uint32_t c1, c2;               // compact lists at pos-1 / at pos-2 (crf kk -> list kk >> 1); `own` already names the target's list
 };
 
-__device__ __forceinline__ void lz_ctx(const DevCode& cd, const Geometry& g, const uint32_t* slot_base, uint32_t pos, uint32_t c, LzCtx* x) {
-  x->M0 = slot_base; x->M1 = slot_base + g.sPar;
-  x->N = g.N; x->sBlk = g.sBlk; x->sCrf = (uint32_t)g.sCrf; x->pw = 2 * g.N; x->m = cd.m; x->R = g.R; x->RS = g.RS;
-  x->lz = cd.rec[pos].lz; x->rp = pos % g.R; x->rsp = g.RS ? pos % g.RS : 0u;
-  x->c = c;
+// byte index, inside a parity buffer, of the back-pointer byte of entry j of conv state `conv` of the list that starts at word
+// `list`: the bytes of a conv state's L entries are adjacent (one L-byte store per thread and odd step)
+__device__ __forceinline__ uint32_t bp_byte_index(const Geometry& g, uint32_t list, uint32_t j, uint32_t conv) {
+  return (list + g.L * g.sBlk) * 4u + conv * g.L + j;
 }
 
-// where the stored message behind pointer p lives: *ent = its message region, *conv / *np = conv state and planes in use there,
-// *S = bits to shift in.  (Uniform fields go through opqs: a select between two loads of the struct would pin it in scratch.)
-__device__ __forceinline__ void lz_resolve(const LzCtx& x, uint32_t p, const uint32_t** ent, uint32_t* conv, uint32_t* np, uint32_t* S) {
-  const uint32_t lz = opqs(x.lz);
-  const uint32_t d = (p >> 16) & 7u, ylow = p >> 19;
-  const uint32_t s = lz_shift(lz, 0, d);
-  *S = s;
-  *conv = ((x.c << s) | ylow) & (x.N - 1u);
-  *np = (lz >> (16u + 3u * d)) & 7u;
-  const uint32_t cm = (lz >> (8u + d)) & 1u;
-  const bool spare = ((p >> 15) & 1u) != 0;
-  const uint32_t r0 = sel(spare, opqs(x.rsp), opqs(x.rp)), rn = sel(spare, opqs(x.RS), opqs(x.R));
-  uint32_t ring = r0 - d;
-  ring += ((int32_t)ring < 0) ? rn : 0u;
-  ring += spare ? opqs(x.R) : 0u;
-  const uint32_t lst = mul24(ring * 8u + (((p >> 3) & 7u) >> cm), x.sCrf) + mul24(p & 7u, x.sBlk);
+// message buffer that holds the message of step t-1's entry of list i (odd steps)
+__device__ __forceinline__ uint32_t lazy_mbuf(const LazyCtx& x, uint32_t i) {
+  return sel(i != 0 && opqs(x.stale_pos1) != 0, opqs(x.stale_mb), opqs(x.fb));
+}
+
+// Where the stored message behind candidate (list i, index j) of the previous step lives, and the moves to apply to it:
+// *ent = message region, *conv / *np = conv index and planes in use there, (s1, n1) then (s2, nb_p) = shifts and new bits.
+// bp1 = the candidate's own back-pointer byte (anchor steps; ignored at odd steps).  false: the message is empty (t = 0).
+// (Selections between fields of the context go through selv: a select between two loads would pin the struct in scratch.)
+__device__ __forceinline__ bool lazy_locate(const LazyCtx& x, uint32_t i, uint32_t j, uint32_t bp1, const uint32_t** ent, uint32_t* conv,
+                                            uint32_t* np, uint32_t* s1, uint32_t* n1, uint32_t* s2) {
+  const uint32_t kk = i == 0 ? x.k : list_crf(x.k, i);
+  const uint32_t own = opq(x.own), c = opq(x.c), cp = opq(x.cp);
+  const uint32_t src = opqs(x.src), src2 = opqs(x.src2);                         // (uniform over the workgroup)
+  const uint32_t np_p = opqs(x.np_p), np_p1 = opqs(x.np_p1), np_p2 = opqs(x.np_p2), sh_p = opqs(x.sh_p);
   const uint32_t* M0 = opqs(x.M0); const uint32_t* M1 = opqs(x.M1);
-  *ent = sel(((p >> 14) & 1u) != 0, M1, M0) + lst + x.pw;
+  *s1 = 0; *n1 = 0;
+  const bool stay = i == 0;
+  if (x.t & 1u) {                                            // odd step: step t-1's entries carry their messages
+    const uint32_t lst = sel(stay, own, src + mul24(kk >> opqs(x.c1), x.sCrf));
+    *ent = sel(lazy_mbuf(x, i) != 0, M1, M0) + lst + mul24(j, x.sBlk) + x.pw;
+    *conv = sel(stay, c, cp); *np = sel(stay, np_p, np_p1); *s2 = sel(stay, 0u, sh_p);
+    return true;
+  }
+  *s2 = sel(stay, 0u, sh_p);
+  if (x.t == 0) { *ent = M0; *conv = 0; *np = 1; return false; }   // the initial entries: empty message
+  const uint32_t i1 = (bp1 >> 3) & 7u, j1 = bp1 & 7u;
+  const bool stay1 = i1 == 0;
+  // four cases: (stay, stay) own state; (stay, move) and (move, stay) the source state at pos-1; (move, move) pos-2
+  const uint32_t y1 = (x.pk1 >> (4 * (kk & 3u))) & 7u;
+  const uint32_t cpp = ((cp << x.sh_q) | y1) & (x.N - 1u);
+  const uint32_t crf1 = list_crf(kk, stay1 ? 1u : i1);       // crf of the second hop's source when it is a move
+  const uint32_t c1 = opqs(x.c1), c2 = opqs(x.c2);
+  const uint32_t l_ss = own, l_sm = src + mul24(crf1 >> c1, x.sCrf), l_ms = src + mul24(kk >> c1, x.sCrf), l_mm = src2 + mul24(crf1 >> c2, x.sCrf);
+  const uint32_t lst = sel(stay, sel(stay1, l_ss, l_sm), sel(stay1, l_ms, l_mm));
+  *conv = sel(stay, sel(stay1, c, cp), sel(stay1, cp, cpp));
+  *np = sel(stay, sel(stay1, np_p, np_p1), sel(stay1, np_p1, np_p2));
+  const bool mm = !stay && !stay1;
+  *s1 = sel(mm, opqs(x.sh_q), 0u); *n1 = sel(mm, opq(x.nb_q), 0u);
+  *s2 = sel(stay && stay1, 0u, sh_p);
+  *ent = sel(((bp1 >> 6) & 1u) != 0, M1, M0) + lst + mul24(j1, x.sBlk) + x.pw;
+  return true;
 }
 
-// the S newest message bits of a path that stands in conv state c, newest in bit 0 (the register holds the newest bit on top)
-__device__ __forceinline__ uint32_t lz_newbits(uint32_t c, uint32_t m, uint32_t S) { return (__brev(c) >> (32u - m)) & ((1u << S) - 1u); }
-
-// The message behind pointer p AS IT STANDS IN THE TARGET.  empty (uniform): time step 0, every stored message is empty.
+// Message of candidate (list i, index j) of the previous step AS IT WOULD STAND IN THE TARGET (all moves applied).
 template <int P>
-__device__ __forceinline__ void lz_message(const LzCtx& x, uint32_t p, bool empty, uint32_t (&mw)[2 * P]) {
-  const uint32_t* ent; uint32_t conv, np, S;
-  lz_resolve(x, p, &ent, &conv, &np, &S);
-  if (!empty) load_msg<P>(ent, x.N, conv, np, mw);
+__device__ __forceinline__ void lazy_message(const LazyCtx& x, uint32_t i, uint32_t j, uint32_t bp1, uint32_t (&mw)[2 * P]) {
+  const uint32_t* ent; uint32_t conv, np, s1, n1, s2;
+  if (lazy_locate(x, i, j, bp1, &ent, &conv, &np, &s1, &n1, &s2)) load_msg<P>(ent, x.N, conv, np, mw);
   else {
 #pragma unroll
     for (int w = 0; w < 2 * P; ++w) mw[w] = 0;
   }
-  push_var<2 * P>(mw, S, lz_newbits(x.c, x.m, S));
+  push_var<2 * P>(mw, s1 + s2, (n1 << s2) | (s2 ? x.nb_p : 0u));     // both moves in one funnel shift per word
 }
 
-// 16-bit word index, inside a parity buffer, of the pointer of entry j of conv state `conv` of the list that starts at word `list`:
-// the pointers of a conv state's L entries are adjacent (one 2L-byte store per thread and step)
-__device__ __forceinline__ uint32_t lz_slot_index(const Geometry& g, uint32_t list, uint32_t j, uint32_t conv) {
-  return (list + g.L * g.sBlk) * 2u + conv * g.L + j;
-}
-
-// what a time step is in lazy mode
-__device__ __forceinline__ uint32_t lz_class(const Geometry& g, uint32_t t) { return t & (g.lazy - 1u); }           // 0 = anchor (K is 2 or 4)
-__device__ __forceinline__ uint32_t lz_anchor_buf(const Geometry& g, uint32_t t) { return (t >> (g.lazy == 4u ? 2 : 1)) & 1u; }   // message buffer of anchor step t (or of the last anchor before t)
-
-// Where the pointers of a target's candidates come from (uniform over the workgroup).
-struct LzSrc {
-  uint32_t stay_msg, move_msg;   // the row of the stay list / of the source lists carries messages (written by an anchor step, or stale):
-                                 // fresh pointers start there; otherwise its entries' stored pointers are composed
-  uint32_t stay_kind, move_kind; // ... and where those messages are (0 / 1: message buffer, 2 | parity: spare rows)
-  uint32_t stale;                // the row of the source lists is older than step t-1 (always with messages of its own)
-  uint32_t empty;                // time step 0: messages are empty
-};
-__device__ __forceinline__ void lz_src(const Geometry& g, const SlotStep& ss, uint32_t pos, LzSrc* s) {
-  const uint32_t cls = lz_class(g, ss.t);
-  const uint32_t fresh = lz_anchor_buf(g, ss.t - 1u);                  // (rows written by step t-1 when that was an anchor)
-  const bool stale = pos == ss.lo && (ss.flags & kLzStale);
-  const uint32_t sk = (ss.flags >> kLzKindShift) & 3u;
-  const uint32_t stale_kind = sk >= 2u ? (2u | (ss.t & 1u)) : sk;    // spare rows of the previous buffer (parity t & 1)
-  const bool prev_anchor = cls == 1u || ss.t == 0;
-  s->empty = ss.t == 0 ? 1u : 0u;
-  s->stale = stale ? 1u : 0u;
-  s->stay_msg = prev_anchor ? 1u : 0u; s->stay_kind = ss.t == 0 ? 0u : fresh;
-  s->move_msg = (prev_anchor || stale) ? 1u : 0u; s->move_kind = ss.t == 0 ? 0u : (stale ? stale_kind : fresh);
-}
-
-// Word offset from a list of row `pos` of the buffer step t writes to its copy in the spare rows (modulo 2^32: added to an offset
-// inside a parity buffer), or 0 when `pos` is not the row the host marked for copying at this step (SlotStep.flags: a later step
-// reads it stale).  Never at an anchor step, whose rows carry messages anyway.
-__device__ __forceinline__ uint32_t lz_spare_delta(const Geometry& g, const SlotStep& ss, uint32_t pos) {
-  const uint32_t mat = (ss.flags >> kLzMatShift) & 3u;
-  if (!mat || pos != ss.lo + mat - 1u || lz_class(g, ss.t) == 0) return 0u;
-  return (uint32_t)(((uint64_t)(g.R + pos % g.RS) - (uint64_t)(pos % g.R)) * 8u * g.sCrf);
-}
-
-// the same move on a pointer in its 16-bit memory form (steps between anchors: d stays <= 3, ylow within its six bits)
-__device__ __forceinline__ uint32_t lz16_move(uint32_t st, uint32_t y, uint32_t lz) {
-  const uint32_t d = (st >> 6) & 3u;
-  return st + (1u << 6) + (y << (8u + lz_shift(lz, 1, d)));
-}
-
-// Are the messages behind pointers pa and pb, as they stand in the target, the same?  For code that runs under a per-lane
-// condition (confirmations): both messages are requested TOGETHER, and when every active lane finds the same plane count on
-// both sides -- all but two or three positions of a read -- behind uniform branches only: one round trip per confirmation (a
-// load behind a per-lane branch costs a drain of the memory queue: DESIGN.md, round 5).
-template <int P>
-__device__ __forceinline__ bool lz_same_message(const LzCtx& x, uint32_t pa, uint32_t pb, bool empty) {
-  const uint32_t* ea; const uint32_t* eb; uint32_t ca, cb, na, nb, Sa, Sb;
-  lz_resolve(x, pa, &ea, &ca, &na, &Sa);
-  lz_resolve(x, pb, &eb, &cb, &nb, &Sb);
-  uint32_t ma[2 * P], mb[2 * P];
-#pragma unroll
-  for (int w = 0; w < 2 * P; ++w) { ma[w] = 0; mb[w] = 0; }
-  if (!empty) {
-    const uint32_t n0 = opqs(na);
-    if (__builtin_amdgcn_ballot_w64(na != n0 || nb != n0) == 0ull) {
-      if (n0 == 1) { load_msg_np<P, 1>(ea, x.N, ca, ma); load_msg_np<P, 1>(eb, x.N, cb, mb); }
-      else if (n0 == 2) { load_msg_np<P, 2>(ea, x.N, ca, ma); load_msg_np<P, 2>(eb, x.N, cb, mb); }
-      else if (n0 == 3) { load_msg_np<P, 3>(ea, x.N, ca, ma); load_msg_np<P, 3>(eb, x.N, cb, mb); }
-      else { load_msg_np<P, 4>(ea, x.N, ca, ma); load_msg_np<P, 4>(eb, x.N, cb, mb); }
-    } else {
-      load_msg<P>(ea, x.N, ca, na, ma);
-      load_msg<P>(eb, x.N, cb, nb, mb);
-    }
-  }
-  const uint32_t nbits = __brev(x.c) >> (32u - x.m);
-  push_var<2 * P>(ma, Sa, nbits & ((1u << Sa) - 1u));
-  push_var<2 * P>(mb, Sb, nbits & ((1u << Sb) - 1u));
-  bool same = true;
-#pragma unroll
-  for (int w = 0; w < 2 * P; ++w) same &= (ma[w] == mb[w]);
-  return same;
+__device__ __forceinline__ void lazy_ctx(const DevCode& cd, const Geometry& g, const SlotStep& ss, const uint32_t* slot_base, uint32_t pos,
+                                         uint32_t c, uint32_t cp, uint32_t k, uint32_t own, LazyCtx* x, int pk1_known = -1) {
+  x->M0 = slot_base; x->M1 = slot_base + g.sPar;
+  x->bp_prev = reinterpret_cast<const uint8_t*>(slot_base + (uint64_t)(ss.t & 1u) * g.sPar);
+  x->N = g.N; x->sBlk = g.sBlk; x->sCrf = (uint32_t)g.sCrf; x->pw = 2 * g.N; x->m = cd.m;
+  x->c = c; x->cp = cp; x->k = k; x->own = own;
+  x->src = (uint32_t)((uint64_t)((pos + g.R - 1) % g.R) * 8 * g.sCrf);
+  x->src2 = (uint32_t)((uint64_t)((pos + g.R - 2) % g.R) * 8 * g.sCrf);
+  const PosRec pr = cd.rec[pos];           // (one scalar load; pos >= 1 here)
+  const uint32_t Tp = pr.info & 0xFFu;
+  x->sh_p = Tp == 0 ? 1u : 2u;
+  x->nb_p = x->sh_p == 1 ? (c >> (cd.m - 1)) : (2 * ((c >> (cd.m - 2)) & 1u) + (c >> (cd.m - 1)));
+  const uint32_t Tq = (pr.info >> 8) & 0xFFu;
+  x->sh_q = Tq == 0 ? 1u : 2u;
+  x->nb_q = x->sh_q == 1 ? (cp >> (cd.m - 1)) : (2 * ((cp >> (cd.m - 2)) & 1u) + (cp >> (cd.m - 1)));
+  // (pk1_known >= 0: the caller's tile_target has read this word already -- wherever the target has a source list at all)
+  x->pk1 = pk1_known >= 0 ? (uint32_t)pk1_known : (pos >= 2 && !(ss.t & 1u)) ? (uint32_t)LVA_GLOBAL(uint16_t, pr.pred1)[cp] : 0u;
+  x->np_p = (pr.info >> 16) & 0xFFu; x->np_p1 = pr.info >> 24; x->np_p2 = pr.np2;
+  x->c1 = (cmp_bits(g, pr) >> 1) & 1u; x->c2 = (cmp_bits(g, pr) >> 2) & 1u;
+  x->t = ss.t; x->fb = ((ss.t - 1u) >> 1) & 1u;
+  x->stale_pos1 = (pos == ss.lo) && (ss.flags & 1u);
+  x->stale_mb = (ss.flags >> 1) & 1u;
 }
 
 // Output phase of one target on the lazy path.  false = a fingerprint match did not survive the comparison of the
 // full messages (collision): the exact path redoes the target.
-// CLS: 0 = anchor step (messages stored), 1 = the step after an anchor (every source row carries messages: fresh pointers
-// start there), 2 = any other step.  own_lo / own_hi: the pointers of the target's own (stay) list in the previous buffer, entry j in
-// bits 16 (j & 3) of own_lo (j < 4) / own_hi; s_ptr: those of the source lists, staged as s_src is.
-template <int LL, int P, int CLS>
-__device__ __forceinline__ bool lazy_output(const Geometry& g, const LzCtx& x, const LzSrc& sr, uint32_t* __restrict__ cur, uint32_t* __restrict__ mout,
-                                            const uint16_t* s_ptr, uint32_t k, uint32_t own, uint32_t sc, uint32_t y, uint32_t crow,
-                                            unsigned long long own_lo, unsigned long long own_hi, unsigned long long asrc,
-                                            unsigned long long rej0, uint32_t lc, uint32_t* s_q, uint32_t* s_qn, uint32_t spare) {
+// own_bp: the back-pointer bytes of the target's own (stay) list in the previous buffer, entry j in byte j (anchor steps).
+template <int LL, int P, bool ANCHOR>
+__device__ __forceinline__ bool lazy_output(const Geometry& g, const LazyCtx& x, uint32_t* __restrict__ cur, uint32_t* __restrict__ mout,
+                                            const uint8_t* s_bp, uint32_t sc, unsigned long long own_bp, unsigned long long asrc,
+                                            unsigned long long rej0, uint32_t lc) {
   bool good = true;
-  const bool empty = opqs(sr.empty) != 0;
-  // An unproven match: the two pointers (register form) go to the workgroup's queue -- compared on their messages after the
-  // workgroup's merges by whole wavefronts (lva_step_lazy's tail): a wavefront that compares its own pays a round of gathers and
-  // some 150 instructions per match of its busiest lane, for a handful of active lanes.  Queue full: compared here.
-  auto defer = [&](uint32_t pa, uint32_t pb) __attribute__((always_inline)) {
-    const uint32_t at = atomicAdd(s_qn, 1u);
-    if (at < kLazyQueue) { s_q[3 * at] = pa; s_q[3 * at + 1] = pb; s_q[3 * at + 2] = x.c | (k << 16); }
-    else good &= lz_same_message<P>(x, pa, pb, empty);
+  // the candidate's own back-pointer byte: staged in LDS for source lists, prefetched for the stay list
+  auto bp_of = [&](uint32_t i, uint32_t j) __attribute__((always_inline)) -> uint32_t {
+    if (i == 0) return (uint32_t)(own_bp >> (8 * j)) & 0xFFu;
+    return s_bp[((list_crf(x.k, i) >> opqs(x.c1)) * TS + sc) * LL + j];
   };
-  // the pointer (memory form) of candidate (list i, index j) AS AN ENTRY OF THE TARGET; lz_unpack of it: register form
-  auto cand16 = [&](uint32_t i, uint32_t j) __attribute__((always_inline)) -> uint32_t {
-    if (i == 0) {
-      if (CLS == 1 || opqs(sr.stay_msg)) return lz_synth(j, k, opqs(sr.stay_kind));
-      const unsigned long long w = sel(j >= 4u, own_hi, own_lo);
-      return (uint32_t)(w >> (16u * (j & 3u))) & 0xFFFFu;
+  // the fingerprint match filed under entry l must be the same message as the entry's (mw): anchor steps, where the
+  // entry's message is in registers anyway
+  auto verify = [&](int l, const uint32_t (&mw)[2 * P]) __attribute__((always_inline)) {
+    const uint32_t rec = (uint32_t)(rej0 >> (7 * l)) & 0x7Fu;
+    if (rec & 0x40u) {
+      const uint32_t ri = (rec >> 3) & 7u, rj = rec & 7u;
+      uint32_t qm[2 * P];
+      lazy_message<P>(x, ri, rj, bp_of(ri, rj), qm);
+#pragma unroll
+      for (int w = 0; w < 2 * P; ++w) good &= (qm[w] == mw[w]);
     }
-    uint32_t p;
-    if (CLS == 1 || opqs(sr.move_msg)) p = lz_synth(j, list_crf(k, i), opqs(sr.move_kind));
-    else p = s_ptr[((list_crf(k, i) >> crow) * TS + sc) * LL + j];
-    return lz16_move(p, y, opqs(x.lz));
   };
-  // ... and with the one move more than a stored pointer holds that an anchor step may compose (register form)
-  auto cand = [&](uint32_t i, uint32_t j) __attribute__((always_inline)) -> uint32_t {
-    if (i == 0) {
-      if (opqs(sr.stay_msg)) return lz_synth(j, k, opqs(sr.stay_kind));
-      const unsigned long long w = sel(j >= 4u, own_hi, own_lo);
-      return lz_unpack((uint32_t)(w >> (16u * (j & 3u))) & 0xFFFFu);
-    }
-    const uint32_t p = opqs(sr.move_msg) ? lz_synth(j, list_crf(k, i), opqs(sr.move_kind)) : s_ptr[((list_crf(k, i) >> crow) * TS + sc) * LL + j];
-    return lz_move(lz_unpack(p), y, opqs(x.lz));
-  };
-  uint32_t todo = 0;
+  // Odd steps confirm their fingerprint matches in a loop over the entries that HAVE one (about one per target, rarely more
+  // than three): inside an unrolled entry loop each of the eight `if (match filed under entry l)` blocks runs for the whole
+  // wavefront as soon as one lane has a match there -- always -- so a wavefront executed eight confirmations for one per lane.
+  // (The same loop in the anchor instance, which has every entry's message in registers at some point anyway: -3 %.)
+  auto verify_loop = [&]() __attribute__((always_inline)) {
+    uint32_t todo = 0;
 #pragma unroll
-  for (int l = 0; l < LL; ++l) todo |= ((uint32_t)(rej0 >> (7 * l + 6)) & 1u) << l;
-  if constexpr (CLS != 0) {
-    // ---- a step between anchors: one pointer per accepted entry; no message is touched here ----
-    uint32_t pk[LL / 2];
-#pragma unroll
-    for (int l = 0; l < LL / 2; ++l) pk[l] = 0;
-#pragma unroll
-    for (int l = 0; l < LL; ++l) {
-      if ((uint32_t)l < lc) {
-        const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu;
-        pk[l >> 1] |= cand16(a8 >> 3, a8 & 7u) << (16 * (l & 1));
-      }
-    }
-    // Fingerprint matches, one per accepted entry at most (rej0), in a loop over the entries that HAVE one (about one per target).
-    //   proven   both candidates carry the same pointer: one stored message under one shift.  Otherwise the pair goes to the queue.
-    //   re-base  when the stay candidate survives a match with a candidate that moves in, the entry is given the MOVER's pointer
-    //            (both name the same message): such a pair comes back at every step while both paths live -- the stay entry
-    //            stays, the mover's source entry stays below and moves in again -- and is then proven by pointer equality.
+    for (int l = 0; l < LL; ++l) todo |= ((uint32_t)(rej0 >> (7 * l + 6)) & 1u) << l;
     while (todo) {
       const uint32_t l = (uint32_t)__builtin_ctz(todo);
       todo &= todo - 1u;
       const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0x3Fu, rec = (uint32_t)(rej0 >> (7 * l)) & 0x3Fu;
-      if constexpr (CLS == 1) {
-        // Right after an anchor both candidates' messages are ONE hop away, in rows the anchor wrote: the stay candidate's in the
-        // target's own list, the mover's one position below -- planes in use, buffers and the move are uniform over the workgroup,
-        // which candidate is which differs per lane.  Both are requested together behind uniform branches only and compared here
-        // (no pointer can prove such a pair: every entry of an anchor's rows is its own stored message).
-        if (((a8 >> 3) == 0) != ((rec >> 3) == 0) && !empty) {
-          const uint32_t st = (a8 >> 3) == 0 ? a8 : rec, mv = (a8 >> 3) == 0 ? rec : a8;
-          const uint32_t lz = opqs(x.lz), npa = (lz >> 16) & 7u, npb = (lz >> 19) & 7u, cm1 = (lz >> 9) & 1u;
-          const uint32_t* Ma = opqs(sr.stay_kind) & 1u ? opqs(x.M1) : opqs(x.M0);
-          const uint32_t mk = opqs(sr.move_kind);
-          const uint32_t* Mb = mk & 1u ? opqs(x.M1) : opqs(x.M0);
-          uint32_t rb = opqs(x.rp) - 1u; rb += (int32_t)rb < 0 ? opqs(x.R) : 0u;
-          if (mk & 2u) { rb = opqs(x.rsp) - 1u; rb += (int32_t)rb < 0 ? opqs(x.RS) : 0u; rb += opqs(x.R); }     // (stale row: its copy in the spare rows)
-          const uint32_t S = lz_shift(lz, 0, 1u);
-          uint32_t ma[2 * P], mb[2 * P];
-          load_msg<P>(Ma + own + mul24(st & 7u, x.sBlk) + x.pw, x.N, x.c, npa, ma);
-          load_msg<P>(Mb + mul24(rb * 8u + (list_crf(k, mv >> 3) >> cm1), x.sCrf) + mul24(mv & 7u, x.sBlk) + x.pw, x.N,
-                      ((x.c << S) | y) & (x.N - 1u), npb, mb);
-          push_var<2 * P>(mb, S, lz_newbits(x.c, x.m, S));
+      uint32_t ma[2 * P], mb[2 * P];
+      {
+        // odd step: the pair is a stay entry (the target's own list, message where the last anchor step put it) and an entry of one
+        // source list (two source lists: 5 in 100 000, the general path below).  Which is which differs per lane, where they live
+        // does not: planes in use, message buffers and the move are uniform over the workgroup -- both messages are requested
+        // together behind uniform branches only, one round trip per confirmation instead of one per piece.
+        const bool a_stay = (a8 >> 3) == 0, r_stay = (rec >> 3) == 0;
+        if (a_stay != r_stay) {
+          const uint32_t s = a_stay ? (a8 & 7u) : (rec & 7u), f6 = a_stay ? rec : a8;
+          const uint32_t* Mf = opqs(x.fb) ? opqs(x.M1) : opqs(x.M0);
+          const uint32_t* Ms = opqs(x.stale_pos1) ? (opqs(x.stale_mb) ? opqs(x.M1) : opqs(x.M0)) : Mf;
+          const uint32_t np_a = opqs(x.np_p), np_b = opqs(x.np_p1);
+          load_msg<P>(Mf + x.own + mul24(s, x.sBlk) + x.pw, x.N, x.c, np_a, ma);
+          load_msg<P>(Ms + opqs(x.src) + mul24(list_crf(x.k, f6 >> 3) >> opqs(x.c1), x.sCrf) + mul24(f6 & 7u, x.sBlk) + x.pw, x.N, x.cp, np_b, mb);
+          push_var<2 * P>(mb, opqs(x.sh_p), x.nb_p);
 #pragma unroll
           for (int w = 0; w < 2 * P; ++w) good &= (ma[w] == mb[w]);
-          if ((a8 >> 3) == 0) {                               // re-base entry l onto the mover's pointer
-            const uint32_t pr = cand16(rec >> 3, rec & 7u);
-            const uint32_t sh = 16u * (l & 1u), keep = ~(0xFFFFu << sh);
-#pragma unroll
-            for (int w = 0; w < LL / 2; ++w) pk[w] = (l >> 1) == (uint32_t)w ? ((pk[w] & keep) | (pr << sh)) : pk[w];
-          }
           continue;
         }
       }
-      const uint32_t pa = cand16(a8 >> 3, a8 & 7u), pr = cand16(rec >> 3, rec & 7u);
-      if (pa != pr) defer(lz_unpack(pa), lz_unpack(pr));
-      if ((a8 >> 3) == 0 && (rec >> 3) != 0) {              // re-base entry l onto the mover's pointer
-        const uint32_t sh = 16u * (l & 1u), keep = ~(0xFFFFu << sh);
+      lazy_message<P>(x, a8 >> 3, a8 & 7u, 0u, ma);
+      lazy_message<P>(x, rec >> 3, rec & 7u, 0u, mb);
 #pragma unroll
-        for (int w = 0; w < LL / 2; ++w) pk[w] = (l >> 1) == (uint32_t)w ? ((pk[w] & keep) | (pr << sh)) : pk[w];
+      for (int w = 0; w < 2 * P; ++w) good &= (ma[w] == mb[w]);
+    }
+  };
+  if constexpr (!ANCHOR) {
+    // ---- odd step: one byte per accepted entry; messages are touched only to confirm fingerprint matches ----
+    unsigned long long packed = 0;
+#pragma unroll
+    for (int l = 0; l < LL; ++l) {
+      if ((uint32_t)l < lc) {
+        const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu;
+        packed |= (unsigned long long)(a8 | (lazy_mbuf(x, a8 >> 3) << 6)) << (8 * l);
       }
     }
-    uint16_t* dst = reinterpret_cast<uint16_t*>(cur) + lz_slot_index(g, own, 0, x.c);
-    if constexpr (LL == 8) *reinterpret_cast<lva_u32x4*>(dst) = lva_u32x4{pk[0], pk[1], pk[2], pk[3]};
-    else if constexpr (LL == 4) *reinterpret_cast<lva_u32x2*>(dst) = lva_u32x2{pk[0], pk[1]};
-    else *reinterpret_cast<uint32_t*>(dst) = pk[0];
-    // The row the host marked (SlotStep.flags; one per slot and step at most -- uniform over the workgroup) will be read STALE by a
-    // later step, whose entries could not compose pointers of another generation: its messages are resolved now and stored in the
-    // spare row  R + pos % RS  of the buffer this step writes; readers of the stale row start fresh pointers there.
-    if (opqs(spare) != 0u) {                               // (spare: word offset from a list of the row to its copy, 0 = not this row)
-#pragma unroll
-      for (int l = 0; l < LL; ++l) {
-        if ((uint32_t)l < lc) {
-          uint32_t mw[2 * P];
-          lz_message<P>(x, lz_unpack((pk[l >> 1] >> (16 * (l & 1))) & 0xFFFFu), empty, mw);
-          store_msg<P>(cur + own + opqs(spare) + l * x.sBlk + x.pw, x.N, x.c, (opqs(x.lz) >> 16) & 7u, mw);
-        }
-      }
-    }
-    return good;
-  } else {
-    // ---- anchor step: ONE gather per accepted entry (its pointer names the stored message), shifted and stored coalesced;
-    //      kLazyInFlight entries in flight ----
-    // (four message planes: one entry in flight -- 8 more message registers would cost the anchor instance a wavefront per SIMD;
-    //  measured at m=14: 4.91 against 4.69 reads/s)
-    while (todo) {                                           // matches: the same pointer, or to the queue
-      const uint32_t l = (uint32_t)__builtin_ctz(todo);
-      todo &= todo - 1u;
-      const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0x3Fu, rec = (uint32_t)(rej0 >> (7 * l)) & 0x3Fu;
-      const uint32_t pa = cand(a8 >> 3, a8 & 7u), pr = cand(rec >> 3, rec & 7u);
-      if (pa != pr) defer(pa, pr);
-    }
-    constexpr int GBW = P >= 4 ? 1 : kLazyInFlight;
-    constexpr int GB = LL >= GBW ? GBW : LL;
-#pragma unroll
-    for (int l0 = 0; l0 < LL; l0 += GB) {
-      uint32_t m[GB][2 * P], sv[GB];
-#pragma unroll
-      for (int u = 0; u < GB; ++u) {
-        const int l = l0 + u;
-        sv[u] = 0;
-#pragma unroll
-        for (int w = 0; w < 2 * P; ++w) m[u][w] = 0;
-        if ((uint32_t)l < lc) {
-          const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu;
-          const uint32_t* ent; uint32_t conv, np;
-          lz_resolve(x, cand(a8 >> 3, a8 & 7u), &ent, &conv, &np, &sv[u]);
-          if (!empty) load_msg<P>(ent, x.N, conv, np, m[u]);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < GB; ++u) {
-        const int l = l0 + u;
-        if ((uint32_t)l < lc) {
-          push_var<2 * P>(m[u], sv[u], lz_newbits(x.c, x.m, sv[u]));
-          store_msg<P>(mout + own + l * x.sBlk + x.pw, x.N, x.c, (opqs(x.lz) >> 16) & 7u, m[u]);
-        }
-      }
-    }
+    uint8_t* dst = reinterpret_cast<uint8_t*>(cur) + bp_byte_index(g, x.own, 0, x.c);
+    if constexpr (LL == 8) *reinterpret_cast<unsigned long long*>(dst) = packed;
+    else if constexpr (LL == 4) *reinterpret_cast<uint32_t*>(dst) = (uint32_t)packed;
+    else *reinterpret_cast<uint16_t*>(dst) = (uint16_t)packed;
+    verify_loop();
     return good;
   }
+  // ---- anchor step: two hops to the stored message, both moves applied, stored coalesced; kLazyInFlight entries in flight ----
+  // (four message planes: one entry in flight -- 8 more message registers would cost the anchor instance a wavefront per SIMD;
+  //  measured at m=14: 4.91 against 4.69 reads/s)
+  constexpr int GBW = P >= 4 ? 1 : kLazyInFlight;
+  constexpr int GB = LL >= GBW ? GBW : LL;
+#pragma unroll
+  for (int l0 = 0; l0 < LL; l0 += GB) {
+    uint32_t m[GB][2 * P], mv[GB];                         // mv: the moves to apply, packed (s1 | n1 << 2 | s2 << 4)
+#pragma unroll
+    for (int u = 0; u < GB; ++u) {
+      const int l = l0 + u;
+      mv[u] = 0;
+#pragma unroll
+      for (int w = 0; w < 2 * P; ++w) m[u][w] = 0;
+      if ((uint32_t)l < lc) {
+        const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu;
+        const uint32_t i = a8 >> 3, j = a8 & 7u;
+        const uint32_t* ent; uint32_t conv, np, s1, n1, s2;
+        if (lazy_locate(x, i, j, bp_of(i, j), &ent, &conv, &np, &s1, &n1, &s2)) load_msg<P>(ent, x.N, conv, np, m[u]);
+        mv[u] = s1 | (n1 << 2) | (s2 << 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < GB; ++u) {
+      const int l = l0 + u;
+      if ((uint32_t)l < lc) {
+        push_var<2 * P>(m[u], (mv[u] & 3u) + (mv[u] >> 4), (((mv[u] >> 2) & 3u) << (mv[u] >> 4)) | ((mv[u] >> 4) ? x.nb_p : 0u));
+        store_msg<P>(mout + x.own + l * x.sBlk + x.pw, x.N, x.c, x.np_p, m[u]);
+        if ((uint32_t)(rej0 >> (7 * l)) & 0x40u) verify(l, m[u]);
+      }
+    }
+  }
+  return good;
 }
 
 }  // namespace
 
-// grid / block as lva_step_fast.  Three instances: CLS = 0 serves the slots at an anchor step (t % K == 0), 1 those at the
-// step after one, 2 the others; the host keeps every slot of a decoder at the same class (reads start on launches that are
-// multiples of K), so a launch runs ONE instance over all slots.  Steps between anchors keep the merge's small register
-// footprint (no message in flight); only the anchor instance gathers messages.  LDS: 32 KB of list heads + 16 KB of slots:
-// three workgroups per CU (four with 8 KB of pointers alone and the posteriors in a register: 8 % faster where nothing else
-// changed, but without the tags half of the fingerprint matches had to be compared on their messages -- measured, round 6).
-template <int LL, int P, int CLS>
+// grid / block as lva_step_fast.  Two instances per step: ANCHOR = true serves the slots whose time step is even,
+// ANCHOR = false those at an odd step (workgroups of the other kind leave at once) -- the odd-step path keeps the
+// merge's small register footprint (no message in flight), the anchor path is the only one that pays for two hops.
+template <int LL, int P, bool ANCHOR>
 __global__ __launch_bounds__(8 * TS, kLazyMinWaves) void lva_step_lazy(StepArgs args, Geometry g, const DevCode* __restrict__ codes,
                                                      uint32_t* __restrict__ trellis, WorkHdr* __restrict__ hdr,
                                                      uint32_t* __restrict__ items) {
   __shared__ uint2 s_src[8 * LL * TS];
-  __shared__ __attribute__((aligned(16))) uint32_t s_ptrw[8 * LL * TS / 2];
+  __shared__ uint8_t s_bp[ANCHOR ? 8 * LL * TS : 4];
   __shared__ float s_post[40];
-  __shared__ uint32_t s_q[3 * kLazyQueue];       // unproven fingerprint matches of the workgroup (lazy_output's defer)
-  __shared__ uint32_t s_qn;
-  if (threadIdx.x == 0) s_qn = 0;
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
     hdr->count[args.step_parity ^ 1u] = 0;     // the other parity's list was consumed by the last fix-up
     hdr->overflow[args.step_parity ^ 1u] = 0;
   }
   SlotStep ss;
   if (!load_slot(args, blockIdx.z, &ss)) return;
-  {
-    const uint32_t cls = lz_class(g, ss.t);
-    if ((cls > 2u ? 2u : cls) != (uint32_t)CLS) return;
-  }
+  if (!(ss.t & 1u) != ANCHOR) return;
   const uint32_t pos = ss.lo + blockIdx.y;
   if (pos >= ss.hi) return;
   const DevCode& cd = codes[ss.orient];
@@ -1651,9 +1533,8 @@ __global__ __launch_bounds__(8 * TS, kLazyMinWaves) void lva_step_lazy(StepArgs 
   uint32_t* slot_base = trellis + (uint64_t)ss.slot * g.sSlot;
   const uint32_t* prev; uint32_t* cur;
   slot_buffers(ss, g, trellis, &prev, &cur);
-  uint32_t* mout = slot_base + (uint64_t)lz_anchor_buf(g, ss.t) * g.sPar;      // message buffer an anchor step writes
-  LzSrc sr;
-  lz_src(g, ss, pos, &sr);
+  constexpr bool anchor = ANCHOR;
+  uint32_t* mout = slot_base + (uint64_t)((ss.t >> 1) & 1u) * g.sPar;      // message buffer an anchor step writes
 
   if (pos == 0) {                          // stay-only update of the 8 start states (:706-713); their message stays empty
     if (tile == cd.init / TS && tid < 8) {
@@ -1662,21 +1543,15 @@ __global__ __launch_bounds__(8 * TS, kLazyMinWaves) void lva_step_lazy(StepArgs 
       const float s = u2f(prev[own_c]) + ss.post_row[(k >= 4 ? 4u : k) * 8 + k];
       cur[own_c] = f2u(s);
       cur[own_c + 1] = prev[own_c + 1];
-      if (CLS == 0) { mout[own + 2 * N + 2 * c] = 0u; mout[own + 2 * N + 2 * c + 1] = 0u; }
-      else {           // stay, entry 0: a fresh pointer after an anchor, the entry's own pointer otherwise
-        const uint16_t* pp = reinterpret_cast<const uint16_t*>(prev);
-        reinterpret_cast<uint16_t*>(cur)[lz_slot_index(g, own, 0, c)] =
-            sr.stay_msg ? (uint16_t)lz_synth(0u, k, sr.stay_kind) : pp[lz_slot_index(g, own, 0, c)];
-        const uint32_t spare = lz_spare_delta(g, ss, 0u);    // (row 0 marked for the spare rows: the empty message)
-        if (spare) { cur[own + spare + 2 * N + 2 * c] = 0u; cur[own + spare + 2 * N + 2 * c + 1] = 0u; }
-      }
+      if (anchor) { mout[own + 2 * N + 2 * c] = 0u; mout[own + 2 * N + 2 * c + 1] = 0u; }
+      else reinterpret_cast<uint8_t*>(cur)[bp_byte_index(g, own, 0, c)] = (uint8_t)((((ss.t - 1u) >> 1) & 1u) << 6);   // stay, entry 0
       for (int l = 1; l < LL; ++l) cur[own_c + l * g.sBlk] = kNegInfBits;
     }
     return;
   }
 
   if (!tile_has_target(args, cd, pos, tile)) return;     // (first / last positions: most tiles have no valid target)
-  // ---- stage the (score, fingerprint) pairs of 64 source conv states and, where their row carries pointers, those:
+  // ---- stage the (score, fingerprint) pairs of 64 source conv states (and, for an anchor step, their back-pointer bytes):
   //      8 crf lists, or the 4 compact lists of a one-bit source position (all of them data) ----
   const uint32_t src = (uint32_t)((uint64_t)((pos - 1) % g.R) * 8 * g.sCrf);
   const uint32_t crow = source_compact(g, cd, ss, blockIdx.y, pos);
@@ -1687,69 +1562,46 @@ __global__ __launch_bounds__(8 * TS, kLazyMinWaves) void lva_step_lazy(StepArgs 
                                                     2 * (tile * TS) + 4 * lane2);
     *reinterpret_cast<uint4*>(&s_src[rowi * TS + 2 * lane2]) = v;
   }
-  if (CLS != 1 && !sr.move_msg) {         // per crf: the L pointers of 64 conv states = 2 TS LL contiguous bytes
-    constexpr uint32_t kW = TS * LL / 2;   // words per crf
-    if constexpr (kW % 4 == 0) {
-      for (uint32_t chunk = tid; chunk < nrow * (kW / 4); chunk += 8u * TS) {
-        const uint32_t kk = chunk / (kW / 4), q = chunk % (kW / 4);
-        *reinterpret_cast<uint4*>(&s_ptrw[kk * kW + 4 * q]) =
-            *reinterpret_cast<const uint4*>(prev + src + (uint64_t)kk * g.sCrf + (uint64_t)LL * g.sBlk + (tile * TS * LL) / 2 + 4 * q);
-      }
-    } else {
-      for (uint32_t chunk = tid; chunk < nrow * kW; chunk += 8u * TS) {
-        const uint32_t kk = chunk / kW, w = chunk % kW;
-        s_ptrw[kk * kW + w] = prev[src + (uint64_t)kk * g.sCrf + (uint64_t)LL * g.sBlk + (tile * TS * LL) / 2 + w];
-      }
+  if (anchor && ss.t != 0) {              // per crf: the L bytes of 64 conv states = TS*LL contiguous bytes
+    constexpr uint32_t kW = TS * LL / 4;   // words per crf
+    for (uint32_t chunk = tid; chunk < nrow * kW; chunk += 8u * TS) {
+      const uint32_t kk = chunk / kW, w = chunk % kW;
+      const uint32_t v = prev[src + (uint64_t)kk * g.sCrf + (uint64_t)LL * g.sBlk + (tile * TS * LL) / 4 + w];
+      *reinterpret_cast<uint32_t*>(&s_bp[kk * TS * LL + 4 * w]) = v;
     }
   }
   if (tid < 40) s_post[tid] = LVA_GLOBAL(float, ss.post_row)[tid];
   __syncthreads();
 
-  LzCtx x;
-  lz_ctx(cd, g, slot_base, pos, 0u, &x);
   TileTarget t;
-  const bool has_target = tile_target<TS>(cd, g, ss, pos, tile, tid, &t);
+  if (!tile_target<TS>(cd, g, ss, pos, tile, tid, &t)) return;
+  // an anchor step needs the back-pointer bytes of its own (stay) list: requested now, used after the merge
+  unsigned long long own_bp = 0;
+  if (anchor && ss.t != 0 && (t.ok & 1u)) {
+    const uint8_t* bpp = reinterpret_cast<const uint8_t*>(prev) + bp_byte_index(g, t.own, 0, t.c);
+    if constexpr (LL == 8) own_bp = *reinterpret_cast<const unsigned long long*>(bpp);
+    else if constexpr (LL == 4) own_bp = *reinterpret_cast<const uint32_t*>(bpp);
+    else own_bp = *reinterpret_cast<const uint16_t*>(bpp);
+  }
   unsigned long long asrc = 0, rej0 = 0;
   uint32_t lc = 0;
-  int why = 0;
-  if (has_target)
-    why = t.k < 4 ? fast_merge_core<LL, 8>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &lc, crow)
-                  : fast_merge_core<LL, 2>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &lc, crow);
-  if (has_target && !why) {
-    x.c = t.c;
-    const uint32_t y = t.cp & ((1u << t.sh) - 1u);       // the register bits the move into (pos, c) lost
-    // the pointers of the target's own (stay) list (requested here, not ahead of the merge: registers that would have to live
-    // through its loop are registers spilled)
-    unsigned long long own_lo = 0, own_hi = 0;
-    if (CLS != 1 && !sr.stay_msg && (t.ok & 1u)) {
-      const uint16_t* pp = reinterpret_cast<const uint16_t*>(prev) + lz_slot_index(g, t.own, 0, t.c);
-      if constexpr (LL == 8) { const lva_u32x4 v = *LVA_GLOBAL(lva_u32x4, pp); own_lo = ((unsigned long long)v.y << 32) | v.x; own_hi = ((unsigned long long)v.w << 32) | v.z; }
-      else if constexpr (LL == 4) { const lva_u32x2 v = *LVA_GLOBAL(lva_u32x2, pp); own_lo = ((unsigned long long)v.y << 32) | v.x; }
-      else own_lo = *LVA_GLOBAL(uint32_t, pp);
-    }
-    if (!lazy_output<LL, P, CLS>(g, x, sr, cur, mout, reinterpret_cast<const uint16_t*>(s_ptrw), t.k, t.own, t.sc, y, crow, own_lo, own_hi, asrc, rej0,
-                                 lc, s_q, &s_qn, lz_spare_delta(g, ss, pos))) why = 4;
+  int why = t.k < 4 ? fast_merge_core<LL, 8>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &lc, crow)
+                    : fast_merge_core<LL, 2>(g, prev, cur, s_src, s_post, t.k, t.c, t.sc, t.own, t.ok, t.fpc, &asrc, &rej0, &lc, crow);
+  if (!why) {
+    LazyCtx x;
+    lazy_ctx(cd, g, ss, slot_base, pos, t.c, t.cp, t.k, t.own, &x, ANCHOR ? (int)t.pk1 : 0);
+    if (!lazy_output<LL, P, ANCHOR>(g, x, cur, mout, s_bp, t.sc, own_bp, asrc, rej0, lc)) why = 4;
   }
-  auto to_work_list = [&](int reason, uint32_t k, uint32_t c) __attribute__((always_inline)) {
-    atomicAdd(&hdr->reason[reason - 1], 1ull);
+  if (why) {
+    atomicAdd(&hdr->reason[why - 1], 1ull);
     const uint32_t idx = atomicAdd(&hdr->count[args.step_parity], 1u);
-    if (idx < hdr->cap) items[idx] = make_item(cd.m, blockIdx.z, blockIdx.y, k, c);
+    if (idx < hdr->cap) items[idx] = make_item(cd.m, blockIdx.z, blockIdx.y, t.k, t.c);
     else hdr->overflow[args.step_parity] = 1u;
-  };
-  if (why) to_work_list(why, t.k, t.c);
-  // ---- the workgroup's unproven fingerprint matches, compared on their messages by whole wavefronts: a pair that differs is a
-  //      collision, its target goes to the exact path (which rewrites whatever the fast path stored for it) ----
-  __syncthreads();
-  const uint32_t nq = s_qn < kLazyQueue ? s_qn : kLazyQueue;
-  for (uint32_t e = tid; e < nq; e += 8u * TS) {
-    const uint32_t w2 = s_q[3 * e + 2];
-    x.c = w2 & 0xFFFFu;
-    if (!lz_same_message<P>(x, s_q[3 * e], s_q[3 * e + 1], sr.empty != 0)) to_work_list(4, w2 >> 16, w2 & 0xFFFFu);
   }
 }
 
 // exact path behind lva_step_lazy: one wavefront per queued target, the reference merge (:743-800) on lane-resident values
-// as fixup_small, messages resolved through the candidates' pointers (lz_message).
+// as fixup_small, messages resolved through lazy_message.
 template <int P>
 __global__ __launch_bounds__(256) void lva_step_fixup_lazy(StepArgs args, Geometry g, const DevCode* __restrict__ codes,
                                                            uint32_t* __restrict__ trellis, WorkHdr* __restrict__ hdr,
@@ -1790,31 +1642,22 @@ __global__ __launch_bounds__(256) void lva_step_fixup_lazy(StepArgs args, Geomet
     const uint32_t* prev; uint32_t* cur;
     slot_buffers(ss, g, trellis, &prev, &cur);
     uint32_t* slot_base = trellis + (uint64_t)ss.slot * g.sSlot;
-    uint32_t* mout = slot_base + (uint64_t)lz_anchor_buf(g, ss.t) * g.sPar;
+    uint32_t* mout = slot_base + (uint64_t)((ss.t >> 1) & 1u) * g.sPar;
     Target tg;
     if (!resolve_target(cd, g, ss, pos, c, k, &tg)) continue;   // (uniform per wavefront)
     if (pos == 0) continue;                // the fast kernel's stay-only update of position 0 is exact
-    LzCtx x;
-    lz_ctx(cd, g, slot_base, pos, tg.c, &x);
-    LzSrc sr;
-    lz_src(g, ss, pos, &sr);
-    const bool anchor = lz_class(g, ss.t) == 0;
-    const bool empty = sr.empty != 0;
-    const uint32_t ymove = tg.cp & ((1u << tg.shift) - 1u);
-    // 1. candidates: lane = list*8 + index; cb = the candidate's pointer as an entry of the target
+    LazyCtx x;
+    lazy_ctx(cd, g, ss, slot_base, pos, tg.c, tg.cp, k, tg.own, &x);
+    const bool anchor = !(ss.t & 1u);
+    // 1. candidates: lane = list*8 + index
     float cs = NEG; uint32_t cy = 0, cb = 0;
     {
       const uint32_t i = lane >> 3, j = lane & 7u;
       if (i < tg.nlists && ((tg.okmask >> i) & 1u) && j < L) {
-        const uint32_t kk = i == 0 ? k : list_crf(k, i);
-        const uint32_t lst = i == 0 ? tg.own : tg.src + (kk >> tg.csrc) * sCrf;
-        const uint32_t cv = i == 0 ? tg.c : tg.cp;
-        const uint2 v = *reinterpret_cast<const uint2*>(prev + lst + j * sBlk + 2 * cv);
+        const uint32_t lst = i == 0 ? tg.own : tg.src + (list_crf(k, i) >> tg.csrc) * sCrf;
+        const uint2 v = *reinterpret_cast<const uint2*>(prev + lst + j * sBlk + 2 * (i == 0 ? tg.c : tg.cp));
         cs = u2f(v.x); cy = i != 0 ? v.y ^ tg.fpc : v.y;
-        const bool msg_row = i == 0 ? sr.stay_msg != 0 : sr.move_msg != 0;
-        uint32_t p = lz_synth(j, kk, i == 0 ? sr.stay_kind : sr.move_kind);
-        if (!msg_row) p = lz_unpack(reinterpret_cast<const uint16_t*>(prev)[lz_slot_index(g, lst, j, cv)]);
-        cb = i == 0 ? p : lz_move(p, ymove, x.lz);
+        if (anchor && ss.t != 0) cb = x.bp_prev[bp_byte_index(g, lst, j, i == 0 ? tg.c : tg.cp)];
       }
     }
     float addv = 0.0f;
@@ -1822,7 +1665,7 @@ __global__ __launch_bounds__(256) void lva_step_fixup_lazy(StepArgs args, Geomet
     // word w of the candidate message of entry (li, lj): every lane computes the whole message and picks its word
     auto word_of = [&](uint32_t li, uint32_t lj, uint32_t w) -> uint32_t {
       uint32_t mw[2 * P];
-      lz_message<P>(x, rdu(cb, li * 8 + lj), empty, mw);
+      lazy_message<P>(x, li, lj, rdu(cb, li * 8 + lj), mw);
       uint32_t v = 0;
 #pragma unroll
       for (int u = 0; u < 2 * P; ++u) v = w == (uint32_t)u ? mw[u] : v;
@@ -1901,29 +1744,18 @@ __global__ __launch_bounds__(256) void lva_step_fixup_lazy(StepArgs args, Geomet
       if (e < L && w == 0)
         *reinterpret_cast<uint2*>(cur + tg.own + e * sBlk + 2 * tg.c) = e < l ? make_uint2(f2u(es), ey) : make_uint2(kNegInfBits, 0u);
       const uint32_t li = (ex >> 16) & 7u, lj = ex & 7u;
-      const uint32_t p1 = (uint32_t)__shfl((int)cb, (int)(li * 8 + lj));   // the entry's pointer (per lane: no readlane here)
+      const uint32_t b1 = (uint32_t)__shfl((int)cb, (int)(li * 8 + lj));   // the entry's own back-pointer byte (per lane: no readlane here)
       if (anchor) {
         uint32_t wv2 = 0;
         if (e < l) {
           uint32_t mw[2 * P];
-          lz_message<P>(x, p1, empty, mw);
+          lazy_message<P>(x, li, lj, b1, mw);
 #pragma unroll
           for (int u = 0; u < 2 * P; ++u) wv2 = w == (uint32_t)u ? mw[u] : wv2;
         }
         if (e < l && w < Wd) mout[tg.own + e * sBlk + 2 * g.N + msg_word_off(g.N, tg.c, w, tg.np_dst)] = wv2;
-      } else {
-        if (e < l && w == 0) reinterpret_cast<uint16_t*>(cur)[lz_slot_index(g, tg.own, e, tg.c)] = (uint16_t)lz_pack(p1);
-        const uint32_t spare = lz_spare_delta(g, ss, pos);   // the row a later step reads stale: its messages to the spare rows
-        if (spare) {
-          uint32_t wv2 = 0;
-          if (e < l) {
-            uint32_t mw[2 * P];
-            lz_message<P>(x, p1, empty, mw);
-#pragma unroll
-            for (int u = 0; u < 2 * P; ++u) wv2 = w == (uint32_t)u ? mw[u] : wv2;
-          }
-          if (e < l && w < Wd) cur[tg.own + spare + e * sBlk + 2 * g.N + msg_word_off(g.N, tg.c, w, tg.np_dst)] = wv2;
-        }
+      } else if (e < l && w == 0) {
+        reinterpret_cast<uint8_t*>(cur)[bp_byte_index(g, tg.own, e, tg.c)] = (uint8_t)((li << 3) | lj | (lazy_mbuf(x, li) << 6));
       }
     }
   }
@@ -2558,8 +2390,8 @@ __global__ void lva_prepare_step(StepArgs a, const DevCode* __restrict__ codes, 
   if (t < d.nblk) {
     const uint32_t b = d.band[t];
     ss.post_row = d.post + (size_t)t * 40;
-    ss.t = t; ss.lo = b & kBandPosMask; ss.hi = (b >> kBandHiShift) & kBandPosMask; ss.flags = b >> kBandFlagShift;
-    ss.prev_hi = t ? (d.band[t - 1] >> kBandHiShift) & kBandPosMask : 1u;       // what step t-1 wrote (only position 0 is initialised at t = 0)
+    ss.t = t; ss.lo = b & 0xFFFFu; ss.hi = (b >> 16) & 0x3FFFu; ss.flags = b >> 30;
+    ss.prev_hi = t ? (d.band[t - 1] >> 16) & 0x3FFFu : 1u;       // what step t-1 wrote (only position 0 is initialised at t = 0)
     ss.orient = d.orient;
     const DevCode& cd = codes[d.orient];          // (the masks are only read where the geometry has compact lists)
     for (uint32_t p = ss.lo < 2u ? 2u : ss.lo; p < ss.hi && p - ss.lo < 64u; ++p)
@@ -2600,32 +2432,44 @@ __global__ void lva_gather_final(Geometry g, const DevCode* __restrict__ codes, 
   const DevCode& cd = codes[a.orient];
   const uint32_t pos = cd.npos - 1, c = cd.fin;
   const uint32_t* buf = trellis + (uint64_t)a.slot * g.sSlot + (uint64_t)a.parity * g.sPar;
-  if (g.lazy) {      // kernel mode 4: the last step's entries hold messages (an anchor step) or pointers to stored messages
+  if (g.lazy) {      // kernel mode 4: the last step's entries hold messages (even last step) or back-pointer bytes (odd)
     const uint32_t* base = trellis + (uint64_t)a.slot * g.sSlot;
     const uint32_t tl = a.nblk - 1, n = 8 * g.L * g.F;
     uint32_t reach = 0;
-    const uint32_t T = cd.ptype[pos], pk = cd.predtab[T][c];
+    const uint32_t T = cd.ptype[pos], pk = cd.predtab[T][c], sh = T == 0 ? 1u : 2u;
     for (int b = 0; b < 4; ++b) if ((pk >> (4 * b)) & 8u) reach |= (0x11u << b);
     if ((c & cd.vmask[pos]) != cd.vval[pos]) reach = 0;
-    LzCtx x;
-    lz_ctx(cd, g, base, pos, c, &x);
+    const uint32_t nbp = sh == 1 ? (c >> (cd.m - 1)) : (2 * ((c >> (cd.m - 2)) & 1u) + (c >> (cd.m - 1)));
     uint32_t* out = results + (uint64_t)a.read * n;
     for (uint32_t e = threadIdx.x; e < 8 * g.L; e += blockDim.x) {
       const uint32_t k = e / g.L, l = e % g.L;
       uint32_t w[2 + 8];
       w[0] = kNegInfBits;
-      for (uint32_t f = 1; f < 2 + 8; ++f) w[f] = 0;
+      for (uint32_t f = 1; f < g.F; ++f) w[f] = 0;
       const uint32_t own = (uint32_t)(((uint64_t)(pos % g.R) * 8 + (k >> compact_pos(cd, g, pos))) * g.sCrf);
       if ((reach >> k) & 1u) {
         w[0] = buf[own + l * g.sBlk + 2 * c]; w[1] = buf[own + l * g.sBlk + 2 * c + 1];
         if (w[0] != kNegInfBits) {
-          if (lz_class(g, tl) == 0) {            // messages stored by the last (anchor) step
-            const uint32_t* mb = base + (uint64_t)lz_anchor_buf(g, tl) * g.sPar;
+          if (!(tl & 1u)) {                      // messages stored by the last (anchor) step in buffer (tl >> 1) & 1
+            const uint32_t* mb = base + (uint64_t)((tl >> 1) & 1u) * g.sPar;
             for (uint32_t f = 2; f < g.F; ++f) w[f] = msg_word(g, mb, own + l * g.sBlk, c, f - 2, cd.npair[pos]);
-          } else {                               // the entry's pointer names the stored message it descends from
-            uint32_t mw[8];
-            lz_message<4>(x, lz_unpack(reinterpret_cast<const uint16_t*>(buf)[lz_slot_index(g, own, l, c)]), false, mw);
-            for (uint32_t f = 2; f < g.F; ++f) w[f] = mw[f - 2];
+          } else {                               // one hop back: the entry's source in step tl-1
+            const uint32_t bp = reinterpret_cast<const uint8_t*>(buf)[bp_byte_index(g, own, l, c)];
+            const uint32_t i = (bp >> 3) & 7u, j = bp & 7u;
+            const uint32_t* mb = base + (uint64_t)((bp >> 6) & 1u) * g.sPar;
+            uint32_t lst = own, conv = c, np = cd.npair[pos], s1 = 0;
+            if (i != 0) {
+              const uint32_t y = (pk >> (4 * (k & 3u))) & 7u;
+              conv = ((c << sh) | y) & (cd.nconv - 1);
+              lst = (uint32_t)(((uint64_t)((pos - 1) % g.R) * 8 + (list_crf(k, i) >> compact_pos(cd, g, pos - 1))) * g.sCrf);
+              np = cd.npair[pos - 1]; s1 = sh;
+            }
+            uint32_t carry = s1 ? nbp : 0u;
+            for (uint32_t f = 2; f < g.F; ++f) {
+              const uint32_t v = msg_word(g, mb, lst + j * g.sBlk, conv, f - 2, np);
+              w[f] = s1 ? ((v << s1) | carry) : v;
+              carry = s1 ? (v >> (32 - s1)) : 0u;
+            }
           }
         }
       }
@@ -2729,12 +2573,11 @@ int launch_step_fast(const StepArgs& a, const Geometry& g, const DevCode* codes,
   }
   if (g.lazy) {
     dim3 grid(g.N / TS, a.band_max, a.nslots), block(8 * TS);
-    // phase-aligned slots (the host starts every read on a launch that is a multiple of K): all slots are at the same kind of
-    // step -- one instance per launch, no workgroups of the wrong kind
-    const uint32_t cls = a.launch_no & (g.lazy - 1u);
-#define LVA_LAZY_CASE(LLv, Pv) { if (cls == 0) hipLaunchKernelGGL((lva_step_lazy<LLv, Pv, 0>), grid, block, 0, st, a, g, codes, trellis, hdr, items); \
-                                 else if (cls == 1) hipLaunchKernelGGL((lva_step_lazy<LLv, Pv, 1>), grid, block, 0, st, a, g, codes, trellis, hdr, items); \
-                                 else hipLaunchKernelGGL((lva_step_lazy<LLv, Pv, 2>), grid, block, 0, st, a, g, codes, trellis, hdr, items); }
+    // phase-aligned slots (the host starts every read on an even launch): all slots are at an even time step on even launches
+    // and at an odd one on odd launches -- one instance per launch, no workgroups of the wrong kind
+    const bool run_anchor = !a.phase_aligned || !(a.launch_no & 1u), run_odd = !a.phase_aligned || (a.launch_no & 1u);
+#define LVA_LAZY_CASE(LLv, Pv) { if (run_anchor) hipLaunchKernelGGL((lva_step_lazy<LLv, Pv, true>), grid, block, 0, st, a, g, codes, trellis, hdr, items); \
+                                 if (run_odd) hipLaunchKernelGGL((lva_step_lazy<LLv, Pv, false>), grid, block, 0, st, a, g, codes, trellis, hdr, items); }
 #define LVA_LAZY_L(LLv) switch (g.P) { case 1: LVA_LAZY_CASE(LLv, 1); break; case 2: LVA_LAZY_CASE(LLv, 2); break; \
                                       case 3: LVA_LAZY_CASE(LLv, 3); break; case 4: LVA_LAZY_CASE(LLv, 4); break; default: return (int)hipErrorInvalidValue; }
     switch (g.L) {

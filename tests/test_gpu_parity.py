@@ -57,6 +57,15 @@ def test_wave_kernel_matches_oracle(oracle, m, r, msg_len, L, md, n, margin, rc_
 
 
 @pytest.mark.parametrize("kernel", [1, 2, 3])
+def test_list_of_twelve_with_sync_marker_on_every_kernel(oracle, kernel):
+    """a list size between 9 and 64 that is NOT on the record layout (12: plane layout, compact lists at one-bit positions --
+    Geometry::cmp, which resolve_target / wave_target / exact_state must honour), forward and reverse complement, with a sync
+    marker: the exact kernel (1), the big-list kernel + wavefront fix-up (2) and the wavefront kernel (3) against the oracle"""
+    reads = synth.make_reads(6, 2, 62, 4, seed0=77, rc_mode="odd", margin=3.0)
+    _compare(oracle, 6, 2, 62, 12, 20, reads, kernel=kernel, sync_marker="10", sync_period=7)
+
+
+@pytest.mark.parametrize("kernel", [1, 2, 3])
 def test_tie_stress(oracle, kernel):
     """posteriors on a 0.25 grid: exact fp32 score ties everywhere, libstdc++ heap order decides"""
     reads = synth.make_reads(6, 1, 60, 4, seed0=7, rc_mode="odd", margin=3.0, quantum=0.25)

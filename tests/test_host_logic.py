@@ -304,115 +304,3 @@ def test_working_band_keeps_every_state_that_can_matter(oracle, m, r, msg_len, m
                 assert t_k is None and pw - 1 > t_ref + 1, (nblk, t, pw, t_ref, t_k)
         # and it really is smaller where it can be
         assert work[0, 1] <= 2 and work[nblk - 1, 0] >= min(npos - 1, ref[nblk - 1, 1])
-
-
-# ---- kernel mode 4 ("lazy messages"): the host's schedule, simulated row by row ------------------------------------------------
-def _lazy_words(m, r, msg_len, rc, nblk, md, K):
-    L = pkg.load_library()
-    words = np.zeros(nblk, np.uint32)
-    ring, spare = ctypes.c_uint32(), ctypes.c_uint32()
-    st = L.lva_lazy_band_words(m, r, msg_len, int(rc), None, 0, nblk, md, K, words.ctypes.data, ctypes.byref(ring), ctypes.byref(spare))
-    assert st == 0, st
-    return words, ring.value, spare.value
-
-
-def _simulate_lazy_rows(words, npos, K, R, RS):
-    """Row-level model of csrc/lva_kernels.hip "lazy messages": every row version is (position, step that wrote it); a row
-    written between anchors holds pointers to stored messages -- modelled as the set of (store, position, step, depth) its entries
-    may name.  Checks what the kernels take for granted: whenever a pointer is resolved (anchor steps, confirmations, the copy to
-    the spare rows) the row it names still holds THAT version (not overwritten, not aliased by the ring), nobody writes it in
-    the same launch, depths fit the pointer's two bits, and the stale / spare-row flags say what the buffers really hold."""
-    sh = [dict(), dict()]          # parity buffer -> ring index -> (pos, step): score rows (and, with them, the pointer rows)
-    msg = [dict(), dict()]         # message buffer b = message planes of parity buffer b, main ring
-    spare = [dict(), dict()]       # spare rows of parity buffer b
-    refs = {}                      # (pos, step) -> frozenset of (kind, pos_a, step_a, depth) for rows that hold pointers
-    sh[0][0] = (0, -1)             # lva_init_slot: position 0 of buffer 0
-    prev_hi = 1
-
-    def check(ref, t, writing):
-        kind, pa, sa, d = ref
-        store = spare[kind & 1] if kind & 2 else msg[kind & 1]
-        idx = pa % RS if kind & 2 else pa % R
-        assert store.get(idx) == (pa, sa), ("pointer to a row that is gone", t, ref, store.get(idx))
-        assert (kind, idx) not in writing, ("pointer into a row this launch writes", t, ref)
-
-    for t, w in enumerate(words):
-        lo, hi, fl = int(w) & 0x3FF, (int(w) >> 10) & 0x3FF, int(w) >> 20
-        stale, skind, mat = fl & 1, (fl >> 1) & 3, (fl >> 3) & 3
-        cls = t % K
-        prv, cur = t & 1, (t + 1) & 1
-        anchor_buf = (t // K) & 1
-        writing = {(anchor_buf, p % R) for p in range(lo, hi)} if cls == 0 else set()
-        new_refs = {}
-        for p in range(lo, hi):
-            rs = set()
-            # stay list: the row of p in the previous buffer, written by step t-1
-            if t >= 1 and p < prev_hi:
-                assert sh[prv].get(p % R) == (p, t - 1), ("stay row is not fresh", t, p, sh[prv].get(p % R))
-                if (t - 1) % K == 0:
-                    rs.add((((t - 1) // K) & 1, p, t - 1, 0))
-                else:
-                    rs |= refs[(p, t - 1)]
-            # source lists: the row of p-1
-            if t >= 1 and p >= 1 and p - 1 < prev_hi:
-                ver = sh[prv].get((p - 1) % R)
-                assert ver is not None and ver[0] == p - 1, ("source row aliased", t, p, ver)
-                lw = ver[1]
-                if lw == t - 1:
-                    assert not (stale and p == lo), ("flagged stale but fresh", t, p)
-                    if lw % K == 0:
-                        rs.add(((lw // K) & 1, p - 1, lw, 1))
-                    else:
-                        rs |= {(k_, pa, sa, d + 1) for (k_, pa, sa, d) in refs[(p - 1, lw)]}
-                else:
-                    assert p == lo and stale, ("stale row without the flag", t, p, lw)
-                    if lw < 0:
-                        pass                                   # (the initial row: t = 0 only)
-                    elif lw % K == 0:
-                        assert skind == ((lw // K) & 1), ("stale kind", t, skind, lw)
-                        rs.add((skind, p - 1, lw, 1))
-                    else:
-                        assert skind == 2, ("stale kind", t, skind, lw)
-                        assert spare[prv].get((p - 1) % RS) == (p - 1, lw), ("stale row was not copied to the spare rows", t, p, lw)
-                        rs.add((2 | prv, p - 1, lw, 1))
-            for ref in rs:
-                check(ref, t, writing)                         # anchors resolve them; other steps may (confirmations)
-                assert ref[3] <= (4 if cls == 0 else 3), ("pointer depth", t, ref)
-            new_refs[p] = frozenset(rs)
-        for p in range(lo, hi):
-            sh[cur][p % R] = (p, t)
-            if cls == 0:
-                msg[anchor_buf][p % R] = (p, t)
-            else:
-                refs[(p, t)] = new_refs[p]
-        if mat:
-            q = lo + mat - 1
-            assert cls != 0 and lo <= q < hi, ("spare-row flag", t, mat)
-            for ref in refs[(q, t)]:
-                check(ref, t, {(2 | cur, q % RS)})
-            spare[cur][q % RS] = (q, t)
-        prev_hi = hi
-    return True
-
-
-@pytest.mark.parametrize("K", [2, 4])
-def test_lazy_schedule_keeps_every_pointer_resolvable(K):
-    """The band words of kernel mode 4 (lva_lazy_band_words = what decode_impl uploads), simulated on a row-level model of
-    the buffers: bands of every width down to 1, reads from barely longer than the trellis to ten times its length (the band
-    then stands still for many steps: every row below it is read stale again and again), both orientations."""
-    L = pkg.load_library()
-    info = _lib.CodeInfoStruct()
-    rng = np.random.default_rng(K)
-    cases = []
-    for (m, r, msg_len) in [(6, 1, 20), (6, 5, 40), (8, 3, 36), (11, 5, 30), (8, 7, 56), (6, 2, 30)]:
-        while L.lva_code_describe(m, r, msg_len, 0, None, 0, ctypes.byref(info)) != 0:      # (a length that ends on a base boundary)
-            msg_len += 1
-        npos = info.nstate_pos
-        for md in (1, 2, 3, 5, 20, 0xFFFFFFFF):
-            for nblk in sorted({npos + 1, npos + 2, npos + 3, npos + 7, int(1.5 * npos), int(2.3 * npos), 3 * npos, 4 * npos + 1, 10 * npos}
-                               | {int(x) for x in rng.integers(npos + 1, 6 * npos, size=6)}):
-                cases.append((m, r, msg_len, npos, md, nblk))
-    for (m, r, msg_len, npos, md, nblk) in cases:
-        for rc in (0, 1):
-            words, R, RS = _lazy_words(m, r, msg_len, rc, nblk, md, K)
-            assert _simulate_lazy_rows(words, npos, K, R, RS), (m, r, msg_len, md, nblk, rc)
