@@ -427,6 +427,21 @@ def main():
             res["extra_configs"] = [
                 run_extra_config(pkg, synth, np, "configs[3]", 14, 7, 8, ["m14_r7_L8", "m14_r7_L8_rc"], a.extra_reads, devno, build_id),
                 run_extra_config(pkg, synth, np, "configs[4]", 11, 5, 64, ["m11_r5_L64", "m11_r5_L64_rc"], a.extra_reads, devno, build_id)]
+            # line traffic of the big-list kernel per launch (committed counters of the SAME library build, per read-step, scaled to
+            # this run's active slots): FETCH_SIZE x 2 + WRITE_SIZE, and TCC_MISS x 128 B
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r6_traffic.json")))
+                e4, k4 = res["extra_configs"][1], tj["kernels"]["big_rec_64"]
+                if tj.get("build_id") == build_id:
+                    e4["traffic"] = k4["fetch_x2_plus_write"] / k4["slots"] * e4["mean_active_slots"]
+                    e4["traffic_tcc_miss_x128"] = k4["tcc_miss_x128"] / k4["slots"] * e4["mean_active_slots"]
+                    e4["traffic_over_algorithmic"] = [k4["ratio_fetch_x2_plus_write"], k4["ratio_tcc_miss_x128"]]
+                    e4["traffic_source"] = "profiles/r6_traffic.json (PMC passes over the same library build)"
+                else:
+                    e4["traffic"] = None
+                    e4["traffic_source"] = "profiles/r6_traffic.json was measured on build %s, this run is build %s" % (tj.get("build_id"), build_id)
+            except Exception:
+                pass
         if cpu is not None:
             O = cpu["O"]
             # the -t 1 sample runs beside the -t N samples: N is capped so that N + 1 threads never exceed the host's CPUs
