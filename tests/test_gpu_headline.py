@@ -1,7 +1,7 @@
 """The benchmark's operating point inside the -m gpu suite (BASELINE.json configs[1] shape): m=11 r=5/6 L=8 msg_len=180
 reads through the DEFAULT 128 read slots, more reads than slots so that slots are refilled while others are mid-read --
 every list and score against kernel mode 1 (lva_step_exact: one thread per target, the reference merge verbatim, no
-fingerprints, no lazy messages), three of them against the CPU oracle.  Plus the default path for list sizes above 64
+fingerprints, no lazy messages), eight of them against the CPU oracle.  Plus the default path for list sizes above 64
 (lva_step_exact) against the oracle.  Reference: viterbi/viterbi_convolutional_code.cpp:589-858."""
 import numpy as np
 import pytest
@@ -27,7 +27,7 @@ def test_benchmark_shape_through_default_slots(oracle):
         assert not isinstance(g, (int, np.integer)) and not isinstance(w, (int, np.integer)), (i, g, w)
         assert np.array_equal(g[0], w[0]), "read %d: list differs from kernel mode 1" % i
         assert np.array_equal(g[1].view(np.uint32), w[1].view(np.uint32)), "read %d: scores differ from kernel mode 1" % i
-    for i in (0, 5, 133):                                   # noisy forward, noisy rc, clean rc
+    for i in (0, 5, 10, 41, 64, 77, 100, 133):              # noisy / clean, forward / rc, first and second wave of reads through the slots
         wm, ws = oracle.OracleCode(m, r, msg_len, rc=rcs[i]).decode(posts[i], L, md, num_threads=32)
         assert np.array_equal(got[i][0], wm), "read %d: list differs from the oracle" % i
         assert np.array_equal(got[i][1].view(np.uint32), ws.view(np.uint32)), "read %d: scores differ from the oracle" % i
