@@ -220,9 +220,30 @@ static int upload_codes(lva_decoder* d) {
       r.np2 = p >= 2 ? dc[o].npair[p - 2] : 1u;
       auto one_bit = [&](int64_t at) -> uint32_t { return at >= 1 && dc[o].ptype[at] == 0 ? 1u : 0u; };   // compact lists there (Geometry::cmp)
       r.cmp3 = one_bit(p) | one_bit((int64_t)p - 1) << 1 | one_bit((int64_t)p - 2) << 2;
-      r.pad1 = 0;
+      r.xs = 0;
       r.pred = dc[o].predtab[dc[o].ptype[p] & 3]; r.pred1 = dc[o].predtab[dc[o].ptype[q] & 3];
     }
+    // XCD-aware tile order (PosRec::xs; lva_kernels.hip xcd_tile).  A 128-byte line of position p's lists -- 16 consecutive conv
+    // states, line index q = conv / 16 -- is read twice in the launch after the one that wrote it: as the own (stay) list of its
+    // targets by the workgroup at p whose butterfly ends there (tile = q without the bits the step into p shifted in, sh = 1 or 2 of
+    // them), and as a source list by the workgroup (tile q >> 2, p + 1).  With workgroups dealt round-robin over the 8 XCDs
+    // (MI355X_MICROARCH.md, workgroup dispatch: observed, a speed matter only) a workgroup (tile, p) runs on the XCD labelled by
+    // bits xs[p] .. xs[p]+2 of its tile, and both readers share an XCD -- and its L2 -- when xs[p] = xs[p+1] + sh.  Greedy chain
+    // from the largest shift the tile count allows; 0 = the plain order.  Used by the L = 1 kernel only: the list kernels
+    // reach their stay lists too late for the staged rows to be still in L2 (measured: nothing at m=11, -1 % at m=14).
+    auto chain = [&](int tile_bits) {
+      if (tile_bits < 4) return;
+      const uint32_t smax = std::min<uint32_t>((uint32_t)tile_bits - 3u, 2u);   // (larger shifts spread a launch's neighbours over the rows: m=14 -2 %)
+      uint32_t s = smax;
+      for (uint32_t p = 1; p < c.npos; ++p) {
+        dc[o].rec[p].xs = s;
+        const uint32_t sh = c.shift_of(c.ptype[p]);
+        s = s >= sh ? s - sh : smax;
+      }
+    };
+    // (measurements: LVA_NO_XCD_ORDER=1 together with LVA_TESTING=1 keeps the plain order)
+    const char* plain = std::getenv("LVA_NO_XCD_ORDER"); const char* testing = std::getenv("LVA_TESTING");
+    if (!(plain && plain[0] == '1' && testing && testing[0] == '1')) chain(c.mem_conv - 6);
   }
   // Compact lists (Geometry::cmp) store crf state k's list as list k >> 1 at a one-bit position: that needs the reachable bases
   // of every valid conv state there to be a complementary pair ({A,T} or {C,G}).  True of the four built-in generator pairs

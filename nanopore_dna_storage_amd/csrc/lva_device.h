@@ -51,7 +51,10 @@ struct PosRec {                  // everything a workgroup needs to know about t
   const uint16_t* pred1;         // predtab[ptype[pos-1]]
   uint32_t cmp3;                 // compact-list flags (Geometry::cmp): bit 0 = position pos, bit 1 = pos-1, bit 2 = pos-2 is a one-bit
                                  // position >= 1 (its lists are stored four per conv state)
-  uint32_t pad1;
+  uint32_t xs;                   // XCD-aware tile order of the butterfly kernels (lva_kernels.hip xcd_tile): the workgroups (tile, pos) whose
+                                 // blockIdx.x has the same low three bits -- one XCD's share under round-robin dispatch -- are those with
+                                 // equal bits xs .. xs+2 of `tile`; chosen per position so that the rows a workgroup at pos reads as its
+                                 // targets' own (stay) lists are the rows the same XCD's workgroups at pos + 1 stage as source lists
 };
 static_assert(sizeof(PosRec) == 64, "PosRec is one 64-byte scalar load");
 

@@ -201,6 +201,18 @@ __device__ __forceinline__ bool tile_has_target(const StepArgs& a, const DevCode
   return ((tile * Tn) & vmask & mid) == (vval & mid);
 }
 
+// XCD-aware tile order (the L = 1 kernel, lva_step_acs).  Workgroups are dealt round-robin over the chip's 8 XCDs in linear block order
+// (observed, MI355X_MICROARCH.md; nothing but speed rests on it), the grid's x extent -- the tiles -- is a multiple of 8 wherever
+// this is used, so blockIdx.x & 7 labels the XCD.  The tile a workgroup takes carries that label in bits xs .. xs+2 (a bijection
+// of the tiles; xs = 0: tile = blockIdx.x), xs per position from the host (PosRec::xs, lva_api.cpp upload_codes): the rows read as
+// stay entries by the workgroups at pos and as source entries by those at pos + 1 then meet in one XCD's L2.  Measured (round 6,
+// one box, same library): m=11 r=5/6 L=1 443 -> 455 reads/s; the list kernels gain nothing from it (their workgroups reach their
+// stay lists 6-10 us after their neighbours staged the same rows: gone from L2 by then; m=14 L=8 -1 %) and keep the plain order.
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t x, uint32_t xs) {
+  const uint32_t rest = x >> 3, lab = x & 7u;
+  return ((rest >> xs) << (xs + 3u)) | (lab << xs) | (rest & ((1u << xs) - 1u));
+}
+
 // work-list item: (((slot << 8 | band position index) << 3 | crf) << m) | conv
 __device__ __forceinline__ uint32_t make_item(uint32_t m, uint32_t z, uint32_t y, uint32_t k, uint32_t c) {
   return ((((z << 8) | y) << 3 | k) << m) | c;
@@ -1556,24 +1568,64 @@ __global__ __launch_bounds__(8 * TS, kLazyMinWaves) void lva_step_lazy(StepArgs 
   const uint32_t src = (uint32_t)((uint64_t)((pos - 1) % g.R) * 8 * g.sCrf);
   const uint32_t crow = source_compact(g, cd, ss, blockIdx.y, pos);
   const uint32_t nrow = 8u >> crow;
-  for (uint32_t chunk = tid; chunk < nrow * LL * (TS / 2); chunk += 8u * TS) {
-    const uint32_t rowi = chunk / (TS / 2), lane2 = chunk % (TS / 2);       // rowi = crf * LL + l
-    const uint4 v = *reinterpret_cast<const uint4*>(prev + src + (uint64_t)(rowi / LL) * g.sCrf + (uint64_t)(rowi % LL) * g.sBlk +
-                                                    2 * (tile * TS) + 4 * lane2);
-    *reinterpret_cast<uint4*>(&s_src[rowi * TS + 2 * lane2]) = v;
-  }
-  if (anchor && ss.t != 0) {              // per crf: the L bytes of 64 conv states = TS*LL contiguous bytes
-    constexpr uint32_t kW = TS * LL / 4;   // words per crf
-    for (uint32_t chunk = tid; chunk < nrow * kW; chunk += 8u * TS) {
-      const uint32_t kk = chunk / kW, w = chunk % kW;
-      const uint32_t v = prev[src + (uint64_t)kk * g.sCrf + (uint64_t)LL * g.sBlk + (tile * TS * LL) / 4 + w];
-      *reinterpret_cast<uint32_t*>(&s_bp[kk * TS * LL + 4 * w]) = v;
+  // Every request of the workgroup's first phase is in flight before the first LDS write waits: the staging loads (NCH chunks of
+  // 16 bytes per thread: LL / 2 for 8 rows, half of that for the 4 rows of a compact source position -- uniform), at an anchor
+  // step the NBP words of back-pointer bytes, and the posteriors.  Until round 6 these were loops over run-time counts, and such
+  // a loop waits for each load before it asks for the next: four + two + one round trips in a row in front of the barrier, one
+  // now (benchmark 48.3 -> 49.2 reads/s; DESIGN_HISTORY R6).
+  TileTarget t;
+  auto stage = [&](auto nch, auto nbp) __attribute__((always_inline)) {
+    constexpr uint32_t NCH = decltype(nch)::value, NBP = decltype(nbp)::value;
+    static_assert(NCH >= 1 && NCH <= 4 && NBP >= 1 && NBP <= 2, "chunks per thread");
+    constexpr uint32_t kW = TS * LL / 4;   // back-pointer words per crf: the L bytes of 64 conv states = TS*LL contiguous bytes
+    const uint32_t nchunk = nrow * LL * (TS / 2), nbw = nrow * kW;
+    // (named registers, not arrays: the compiler leaves an array it cannot fully scalarise in scratch memory or in LDS)
+    uint4 v0, v1, v2, v3;
+    uint32_t bw0, bw1;
+    float pv;
+    auto src_of = [&](uint32_t u) __attribute__((always_inline)) -> const uint4* {
+      const uint32_t chunk = tid + u * 8u * TS, rowi = chunk / (TS / 2), lane2 = chunk % (TS / 2);       // rowi = crf * LL + l
+      return reinterpret_cast<const uint4*>(prev + src + (uint64_t)(rowi / LL) * g.sCrf + (uint64_t)(rowi % LL) * g.sBlk +
+                                            2 * (tile * TS) + 4 * lane2);
+    };
+    auto dst_of = [&](uint32_t u) __attribute__((always_inline)) -> uint4* {
+      const uint32_t chunk = tid + u * 8u * TS, rowi = chunk / (TS / 2), lane2 = chunk % (TS / 2);
+      return reinterpret_cast<uint4*>(&s_src[rowi * TS + 2 * lane2]);
+    };
+    // (only at LL = 2 can a row block be smaller than the workgroup: no per-lane guard elsewhere)
+    const bool in0 = LL != 2 || tid < nchunk;
+    if (in0) v0 = *src_of(0);
+    if constexpr (NCH > 1) v1 = *src_of(1);
+    if constexpr (NCH > 2) v2 = *src_of(2);
+    if constexpr (NCH > 3) v3 = *src_of(3);
+    auto bp_of = [&](uint32_t u) __attribute__((always_inline)) -> const uint32_t* {
+      const uint32_t chunk = tid + u * 8u * TS;
+      return prev + src + (uint64_t)(chunk / kW) * g.sCrf + (uint64_t)LL * g.sBlk + (tile * TS * LL) / 4 + chunk % kW;
+    };
+    const bool b0 = LL == 8 || tid < nbw;
+    if (anchor && ss.t != 0) {
+      if (b0) bw0 = *bp_of(0);
+      if constexpr (NBP > 1) bw1 = *bp_of(1);
     }
+    if (tid < 40) pv = LVA_GLOBAL(float, ss.post_row)[tid];
+    if (in0) *dst_of(0) = v0;
+    if constexpr (NCH > 1) *dst_of(1) = v1;
+    if constexpr (NCH > 2) *dst_of(2) = v2;
+    if constexpr (NCH > 3) *dst_of(3) = v3;
+    if (anchor && ss.t != 0) {
+      if (b0) *reinterpret_cast<uint32_t*>(&s_bp[(tid / kW) * TS * LL + 4 * (tid % kW)]) = bw0;
+      if constexpr (NBP > 1) *reinterpret_cast<uint32_t*>(&s_bp[((tid + 8u * TS) / kW) * TS * LL + 4 * ((tid + 8u * TS) % kW)]) = bw1;
+    }
+    if (tid < 40) s_post[tid] = pv;
+  };
+  {
+    constexpr uint32_t kCh = (8u * LL * (TS / 2) + 8u * TS - 1u) / (8u * TS);          // LL = 8: 4, LL = 4: 2, LL = 2: 1
+    constexpr uint32_t kBp = (8u * (TS * LL / 4) + 8u * TS - 1u) / (8u * TS);          // LL = 8: 2, else 1
+    if (crow) stage(std::integral_constant<uint32_t, (kCh + 1) / 2>{}, std::integral_constant<uint32_t, (kBp + 1) / 2>{});
+    else stage(std::integral_constant<uint32_t, kCh>{}, std::integral_constant<uint32_t, kBp>{});
   }
-  if (tid < 40) s_post[tid] = LVA_GLOBAL(float, ss.post_row)[tid];
   __syncthreads();
 
-  TileTarget t;
   if (!tile_target<TS>(cd, g, ss, pos, tile, tid, &t)) return;
   // an anchor step needs the back-pointer bytes of its own (stay) list: requested now, used after the merge
   unsigned long long own_bp = 0;
@@ -1780,7 +1832,7 @@ __global__ __launch_bounds__(4 * TS) void lva_step_acs(StepArgs args, Geometry g
   const uint32_t pos = ss.lo + blockIdx.y;
   if (pos >= ss.hi) return;
   const DevCode& cd = codes[ss.orient];
-  const uint32_t N = cd.nconv, tid = threadIdx.x, tile = blockIdx.x;
+  const uint32_t N = cd.nconv, tid = threadIdx.x, tile = xcd_tile(blockIdx.x, cd.rec[pos].xs & 0xFFu);
   const uint32_t* prev; uint32_t* cur;
   slot_buffers(ss, g, trellis, &prev, &cur);
   if (pos == 0) {                          // stay-only update of the 8 start states (:706-713)

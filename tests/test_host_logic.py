@@ -304,3 +304,53 @@ def test_working_band_keeps_every_state_that_can_matter(oracle, m, r, msg_len, m
                 assert t_k is None and pw - 1 > t_ref + 1, (nblk, t, pw, t_ref, t_k)
         # and it really is smaller where it can be
         assert work[0, 1] <= 2 and work[nblk - 1, 0] >= min(npos - 1, ref[nblk - 1, 1])
+
+
+@pytest.mark.parametrize("m,r,rc", [(11, 5, False), (11, 5, True), (11, 1, False), (14, 7, False), (14, 7, True), (8, 3, False)])
+def test_xcd_tile_order_is_a_bijection_and_pairs_the_two_readers_of_a_row(m, r, rc):
+    """The L = 1 kernel's tile order (csrc/lva_kernels.hip xcd_tile, csrc/lva_api.cpp upload_codes `chain`), restated: the workgroup
+    with blockIdx.x = x takes the tile that carries x & 7 -- the label of its XCD under round-robin dispatch -- in bits xs .. xs+2.
+    Whatever xs, that is a bijection of the tiles (correctness rests on nothing else); and where xs[p] = xs[p+1] + (bits of the
+    step into p) the workgroup that reads a 128-byte row of position p as its targets' stay entries and the workgroup at p + 1 that
+    stages the same row as source entries carry the same label."""
+    from nanopore_dna_storage_amd import decoder as dec
+    tab = dec.code_tables(m, r, {5: 180, 1: 100, 7: 182, 3: 164}[r], rc)
+    ptype = tab["ptype"]
+    npos, N = len(ptype), 1 << m
+    tile_bits = m - 6
+    G = 1 << max(tile_bits, 0)
+
+    def xcd_tile(x, xs):
+        rest, lab = x >> 3, x & 7
+        return ((rest >> xs) << (xs + 3)) | (lab << xs) | (rest & ((1 << xs) - 1))
+
+    xs = [0] * npos
+    if tile_bits >= 4:
+        smax = s = min(tile_bits - 3, 2)
+        for p in range(1, npos):
+            xs[p] = s
+            sh = 1 if ptype[p] == 0 else 2
+            s = s - sh if s >= sh else smax
+    else:
+        assert G < 16                                   # fewer than 16 tiles: the plain order
+    for s in set(xs):
+        assert sorted(xcd_tile(x, s) for x in range(G)) == list(range(G))
+    if tile_bits < 4:
+        return
+    label = {}                                          # (pos, tile) -> x & 7 of the workgroup that takes it
+    for p in range(1, npos):
+        for x in range(G):
+            label[(p, xcd_tile(x, xs[p]))] = x & 7
+    paired = 0
+    for p in range(1, npos - 1):
+        sh = 1 if ptype[p] == 0 else 2
+        if xs[p] != xs[p + 1] + sh:
+            continue
+        paired += 1
+        Tn = 64 >> sh
+        for q in range(N // 16):                        # a row piece of 16 conv states = one 128-byte line of 8-byte entries
+            c = 16 * q
+            stay_tile = (c % (N >> sh)) // Tn           # tile_target: c = tile * Tn + i + x * (N >> sh)
+            source_tile = c // 64                       # staged by the workgroup whose 64 source conv states contain c
+            assert label[(p, stay_tile)] == label[(p + 1, source_tile)], (p, q)
+    assert paired >= (npos - 2) // 3
