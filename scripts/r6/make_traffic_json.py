@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """profiles/r6_traffic.json: LINE traffic per launch of the dominant kernels -- the lazy pair of the benchmark AND the big-list
-kernel of configs[4] -- from the committed counter summaries of the library that is shipped (round 6's product library is
-byte-identical to round 5's: build bcc33b9ee275; the counters were taken once, on that build, by scripts/r5/prof_final.sh and
-scripts/r5/pmc.sh), in the two forms MI355X_MICROARCH.md's HBM section asks for:
+kernel of configs[4] -- from the counter summaries of the library that is shipped (taken once, on the final build, by
+scripts/r6/prof_final2.sh: separate --pmc passes), in the two forms MI355X_MICROARCH.md's HBM section asks for:
 
     fetch_x2_plus_write   FETCH_SIZE x 2 (the gfx950 correction) + WRITE_SIZE, bytes
     tcc_miss_x128         TCC_MISS_sum x 128 B: every L2 miss is a line whatever part of it the lane wanted
@@ -10,13 +9,14 @@ scripts/r5/pmc.sh), in the two forms MI355X_MICROARCH.md's HBM section asks for:
 and their ratio to the algorithmic bytes of the same launches.  bench.py fills roofline.traffic (headline) and
 extra_configs[].traffic (configs[4]) from this file when the running library has the same build id.
 
-    python scripts/r6/make_traffic_json.py profiles profiles/r6_traffic.json
+    python scripts/r6/make_traffic_json.py <dir> profiles/r6_traffic.json [prefix of the files in <dir>, default r5]
 """
 import json
 import re
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
+PRE = sys.argv[3] if len(sys.argv) > 3 else "r5"
 
 
 def summary(path):
@@ -53,15 +53,15 @@ def entry(counters, alg_per_launch, launches_weight=None):
             "ratio_raw_counters": (fetch + write) / alg_per_launch, "dispatch_weights": w}
 
 
-lazy = {k: v for k, v in summary(src + "/r5_lazy128_pmc_summary.txt").items() if k.startswith("lva_step_lazy")}
-big = {k: v for k, v in summary(src + "/r5_big64_pmc_summary.txt").items() if k.startswith("lva_step_big_rec")}
-bl, bb = bench(src + "/r5_lazy128_bench_under_pmc.json"), bench(src + "/r5_big64_bench_under_pmc.json")
+lazy = {k: v for k, v in summary(src + "/%s_lazy128_pmc_summary.txt" % PRE).items() if k.startswith("lva_step_lazy")}
+big = {k: v for k, v in summary(src + "/%s_big64_pmc_summary.txt" % PRE).items() if k.startswith("lva_step_big_rec")}
+bl, bb = bench(src + "/%s_lazy128_bench_under_pmc.json" % PRE), bench(src + "/%s_big64_bench_under_pmc.json" % PRE)
 assert bl["library"]["build_id"] == bb["library"]["build_id"]
-r5 = json.load(open(src + "/r5_traffic.json"))
+r5 = json.load(open(src + "/%s_lazy_traffic.json" % PRE if PRE != "r5" else src + "/r5_traffic.json"))
 out = {
     "build_id": bl["library"]["build_id"], "library": bl["library"]["version"],
-    "_comment": "line traffic per launch of the dominant kernels on the shipped library (round 6 = round 5's build, counters of scripts/r5/prof_final.sh "
-                "and scripts/r5/pmc.sh): FETCH_SIZE x 2 + WRITE_SIZE and TCC_MISS x 128 B, both against the algorithmic bytes of the same launches.  "
+    "_comment": "line traffic per launch of the dominant kernels on the shipped library (counters of separate rocprofv3 --pmc passes on the build "
+                "named here): FETCH_SIZE x 2 + WRITE_SIZE and TCC_MISS x 128 B, both against the algorithmic bytes of the same launches.  "
                 "The lazy pair moves FEWER lines than the algorithm counts (no wasted traffic: it is bound by instruction issue and lane-level memory "
                 "operations); the big-list kernel moves 1.7-1.9x the algorithmic lines at ~5 TB/s: it IS line-bound, with about half of the lines wasted "
                 "(every record line fetched twice -- walk, then output -- and partial-line writes).",
