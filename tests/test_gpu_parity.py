@@ -277,3 +277,21 @@ def test_default_slot_count_grows_for_small_trellises():
                               (6, 1, 60, 1, 4096), (8, 1, 100, 1, 1024), (11, 1, 40, 1, 128)):     # L = 1: launches a quarter as long
         with pkg.Decoder(m, r, ml, list_size=L, max_deviation=20) as dec:
             assert dec.profile()["slots"] == want
+
+
+@pytest.mark.parametrize("m,r,msg_len", [(11, 5, 54), (11, 1, 40), (14, 7, 42)])
+def test_list_size_one_xcd_aware_tile_order_and_plain_order(oracle, monkeypatch, m, r, msg_len):
+    """The L = 1 kernel takes its tiles in the XCD-aware order (PosRec::xs, csrc/lva_kernels.hip xcd_tile) wherever there are at
+    least 16 of them; LVA_NO_XCD_ORDER=1 (with LVA_TESTING=1, set by conftest) keeps blockIdx.x order.  Both against the CPU oracle,
+    both orientations, reads through reused slots."""
+    reads = [synth.make_read(m, r, msg_len, 7100 + i, rc=bool(i & 1), margin=2.0 + (i % 3), sub=0.02 * (i == 3)) for i in range(6)]
+    codes = {rc: oracle.OracleCode(m, r, msg_len, rc=rc) for rc in (False, True)}
+    want = [codes[x["rc"]].decode(x["post"], 1, 8) for x in reads]
+    for plain in (False, True):
+        if plain:
+            monkeypatch.setenv("LVA_NO_XCD_ORDER", "1")
+        with pkg.Decoder(m, r, msg_len, list_size=1, max_deviation=8, max_slots=4) as dec:
+            got = dec.decode([x["post"] for x in reads], rc=[x["rc"] for x in reads])
+        for i, (g, (wm, ws)) in enumerate(zip(got, want)):
+            assert not isinstance(g, int), "read %d: error %r" % (i, g)
+            assert np.array_equal(g[0], wm) and np.array_equal(g[1].view(np.uint32), ws.view(np.uint32)), "read %d plain=%s" % (i, plain)
