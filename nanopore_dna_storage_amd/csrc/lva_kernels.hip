@@ -889,6 +889,12 @@ constexpr int kLazyInFlight = 2;         // anchor instance: entries whose messa
 
 
 
+// maximum of three / two floats that are known not to be NaN (the list heads: a NaN sends the target to the exact path before it
+// gets here) -- fmaxf would first quiet each operand that comes straight from memory (one more instruction per operand)
+__device__ __forceinline__ float max3_nn(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float max2_nn(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+constexpr int kRecBits = 8;              // bits per fingerprint-match record in rej0 (valid 0x40 | list << 3 | index), one per accepted entry
+
 // Output phase of fast_merge: gather the surviving messages from HBM, shift in the new bits, store coalesced
 // (:771-774, :780); the fingerprint match filed under an entry must be the same message -- false = a collision,
 // the exact path redoes the target.
@@ -920,7 +926,7 @@ __device__ __forceinline__ bool fast_output(const Geometry& g, const uint32_t* _
         const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0xFFu;
         push_bits<2 * P>(m[u], (a8 >> 3) == 0 ? 0u : sh, nb);      // (push_var here: 76 instead of 68 registers with four planes)
         store_msg<P>(cur + own + l * sBlk + pw, N, c, np_dst, m[u]);
-        const uint32_t rec = (uint32_t)(rej0 >> (7 * l)) & 0x7Fu;
+        const uint32_t rec = (uint32_t)(rej0 >> (kRecBits * l)) & 0x7Fu;
         if (rec & 0x40u) {
           const uint32_t ri = (rec >> 3) & 7u, rj = rec & 7u;
           const uint32_t rfrom = ri == 0 ? own + mul24(rj, sBlk) : src + mul24(list_crf(k, ri), sCrf) + mul24(rj, sBlk);
@@ -984,13 +990,18 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
     if (ok && !(h[i] > NEG)) why = 2;
   }
 
-  // Accepted entries.  ah: their fingerprints, NEWEST FIRST (a shift register: static register
-  // indices only).  asrc: 8 bits (list << 3 | index) per entry in acceptance order.  rej0: the
-  // fingerprint match waiting for verification, filed under the accepted entry it matched,
-  // 7 bits (valid, list, index) per entry -- ONE per entry (see below).
+  // Accepted entries.  ah: their fingerprints, NEWEST FIRST (a shift register: static register indices only) -- bits 31..3 of the
+  // fingerprint with the entry's index l in the low three bits, so that ONE unsigned minimum over (ah[a] ^ candidate) says whether
+  // an accepted entry has the candidate's fingerprint (minimum < 8: the upper 29 bits agree) and which (the minimum itself).  A
+  // match on 29 bits that is none on 32 is confirmed on the full messages like every other and fails there (reason 4).  Empty
+  // slots hold all ones: a candidate whose upper 29 bits are all ones would match them and goes to the exact path (reason 3;
+  // 2^-29 of the pops -- NOT zero, the fingerprint of every all-zero message).
+  // asrc: 8 bits (list << 3 | index) per entry in acceptance order.  rej0: the fingerprint match waiting for verification, filed
+  // under the accepted entry it matched, kRecBits bits (valid 0x40, list, index) per entry -- ONE per entry (see below).
+  constexpr uint32_t kBlank = 0xFFFFFFF8u;
   uint32_t ah[LL];
 #pragma unroll
-  for (int l = 0; l < LL; ++l) ah[l] = 0;
+  for (int l = 0; l < LL; ++l) ah[l] = kBlank;
   unsigned long long asrc = 0, rej0 = 0;
   uint32_t ptr = 0, lc = 0;
 
@@ -998,9 +1009,9 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
   // lanes that are done keep running harmless iterations until the wavefront's last lane exits.
   bool go = why == 0;
   while (go) {                                                         // :764
-    float M = h[0];
-#pragma unroll
-    for (int i = 1; i < NL; ++i) M = fmaxf(M, h[i]);
+    float M;
+    if constexpr (NL == 8) M = max2_nn(max3_nn(max3_nn(max3_nn(h[0], h[1], h[2]), h[3], h[4]), h[5], h[6]), h[7]);
+    else M = max2_nn(h[0], h[1]);
     bool eq[NL];
 #pragma unroll
     for (int i = 0; i < NL; ++i) eq[i] = h[i] == M;
@@ -1037,25 +1048,26 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
       for (int l = 0; l + 1 < LL; ++l) { st_s[l] = opq(st_s[l + 1]); st_h[l] = opq(st_h[l + 1]); }
       st_s[LL - 1] = NEG;
     }
-    // de-duplicate on fingerprints (:778-779): position q in ah <-> accepted entry lc-1-q
-    int q = -1;
+    // de-duplicate on fingerprints (:778-779)
+    const uint32_t chk = ch & ~7u;
+    uint32_t mn = ah[0] ^ chk;
 #pragma unroll
-    for (int a = LL - 1; a >= 0; --a) q = ah[a] == ch ? a : q;
-    const bool isdup = q >= 0 && (uint32_t)q < lc;
-    const bool accept = proceed && !isdup, reject = proceed && isdup;
-    const uint32_t s7 = 7u * (lc - 1u - (uint32_t)q);          // (only meaningful when reject)
-    const unsigned long long rec = (unsigned long long)(0x40u | (sel << 3) | j);
-    const bool full0 = reject && ((rej0 >> (s7 & 63u)) & 0x40u);
+    for (int a = 1; a < LL; ++a) mn = min(mn, ah[a] ^ chk);            // (v_min3_u32)
+    const bool blank = chk == kBlank;
+    const bool isdup = mn < 8u;                                        // mn = index of the accepted entry with this fingerprint
+    const bool accept = proceed && !isdup && !blank, reject = proceed && isdup && !blank;
     // Practically every duplicate pairs an entry of the stay list with an entry of ONE source list: the source lists of a
     // target hardly ever share a message (instrumented oracle, scripts/merge_stats.py: 4-6 in 100 000 duplicate pops at
     // m = 6 / 8 / 11, clean and noisy), so an accepted entry has one match at most.  A second one -- a message in three
-    // lists, or a fingerprint collision -- is reason 3: the exact path decides.
-    rej0 |= (reject && !full0) ? rec << (s7 & 63u) : 0ull;
+    // lists, or a fingerprint collision -- is reason 3: the exact path decides.  Two records filed under one entry merge their
+    // valid bits; the count of valid bits is compared with the count of rejected candidates behind the loop.
+    const uint32_t rec = reject ? (0x40u | (sel << 3) | j) : 0u;
+    rej0 |= (unsigned long long)rec << ((mn << 3) & 56u);
     if (accept) {
       *reinterpret_cast<uint2*>(cur + own_c + mul24(lc, sBlk)) = make_uint2(f2u(M), ch);   // :780-783
 #pragma unroll
       for (int a = LL - 1; a >= 1; --a) ah[a] = opq(ah[a - 1]);
-      ah[0] = ch;
+      ah[0] = chk | lc;
       asrc |= (unsigned long long)((sel << 3) | j) << (8 * lc);
       lc += 1u;
     }
@@ -1063,10 +1075,18 @@ __device__ __forceinline__ int fast_merge_core(const Geometry& g, const uint32_t
 #pragma unroll
     for (int i = 0; i < NL; ++i) h[i] = selv(eq[i], ns, h[i]);
     ptr += 1u << (4 * sel);
-    why = (alive && two) ? 1 : ((proceed && bad) ? 2 : (full0 ? 3 : 0));
+    why = (alive && two) ? 1 : ((proceed && bad) ? 2 : ((proceed && blank) ? 3 : 0));
     go = proceed && why == 0 && lc < (uint32_t)LL;
   }
   if (why) return why;
+  {
+    // candidates popped = the list pointers' sum: accepted + rejected (+ the one pop that found every list exhausted, when the
+    // list is not full); every rejected candidate must have its own record
+    const uint32_t t4 = (ptr & 0x0F0F0F0Fu) + ((ptr >> 4) & 0x0F0F0F0Fu);
+    const uint32_t pops = (t4 * 0x01010101u) >> 24;
+    const uint32_t nrej = pops - lc - (lc < (uint32_t)LL ? 1u : 0u);
+    if ((uint32_t)__builtin_popcountll(rej0 & 0x4040404040404040ull) != nrej) return 3;
+  }
 
   // unused tail of the list (:799)
 #pragma unroll
@@ -1420,7 +1440,7 @@ __device__ __forceinline__ bool lazy_output(const Geometry& g, const LazyCtx& x,
   // the fingerprint match filed under entry l must be the same message as the entry's (mw): anchor steps, where the
   // entry's message is in registers anyway
   auto verify = [&](int l, const uint32_t (&mw)[2 * P]) __attribute__((always_inline)) {
-    const uint32_t rec = (uint32_t)(rej0 >> (7 * l)) & 0x7Fu;
+    const uint32_t rec = (uint32_t)(rej0 >> (kRecBits * l)) & 0x7Fu;
     if (rec & 0x40u) {
       const uint32_t ri = (rec >> 3) & 7u, rj = rec & 7u;
       uint32_t qm[2 * P];
@@ -1436,11 +1456,11 @@ __device__ __forceinline__ bool lazy_output(const Geometry& g, const LazyCtx& x,
   auto verify_loop = [&]() __attribute__((always_inline)) {
     uint32_t todo = 0;
 #pragma unroll
-    for (int l = 0; l < LL; ++l) todo |= ((uint32_t)(rej0 >> (7 * l + 6)) & 1u) << l;
+    for (int l = 0; l < LL; ++l) todo |= ((uint32_t)(rej0 >> (kRecBits * l + 6)) & 1u) << l;
     while (todo) {
       const uint32_t l = (uint32_t)__builtin_ctz(todo);
       todo &= todo - 1u;
-      const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0x3Fu, rec = (uint32_t)(rej0 >> (7 * l)) & 0x3Fu;
+      const uint32_t a8 = (uint32_t)(asrc >> (8 * l)) & 0x3Fu, rec = (uint32_t)(rej0 >> (kRecBits * l)) & 0x3Fu;
       uint32_t ma[2 * P], mb[2 * P];
       {
         // odd step: the pair is a stay entry (the target's own list, message where the last anchor step put it) and an entry of one
@@ -1512,7 +1532,7 @@ __device__ __forceinline__ bool lazy_output(const Geometry& g, const LazyCtx& x,
       if ((uint32_t)l < lc) {
         push_var<2 * P>(m[u], (mv[u] & 3u) + (mv[u] >> 4), (((mv[u] >> 2) & 3u) << (mv[u] >> 4)) | ((mv[u] >> 4) ? x.nb_p : 0u));
         store_msg<P>(mout + x.own + l * x.sBlk + x.pw, x.N, x.c, x.np_p, m[u]);
-        if ((uint32_t)(rej0 >> (7 * l)) & 0x40u) verify(l, m[u]);
+        if ((uint32_t)(rej0 >> (kRecBits * l)) & 0x40u) verify(l, m[u]);
       }
     }
   }
