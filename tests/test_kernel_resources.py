@@ -58,3 +58,18 @@ def test_big_list_output_phase_requests_a_round_at_once(asm):
         run = run + 1 if ln.startswith("global_load") else 0
         best = max(best, run)
     assert best >= 8, best          # four entries x (16 + 16 bytes) at three message planes
+
+
+@pytest.mark.parametrize("inst", ["Lb0", "Lb1"])
+def test_lazy_first_phase_is_one_round_trip(asm, inst):
+    """round 6: every staging request of a thread -- four 16-byte chunks for 8 rows of 8 entries, at an anchor step the two words of
+    back-pointer bytes, the posteriors -- is issued before the first LDS write waits; a loop over a run-time count would be compiled
+    as load, s_waitcnt vmcnt(0), write, next (seven round trips in a row in front of the barrier, as it was until then).  And the
+    merge loop finds a duplicate with unsigned minima over the tagged fingerprints, not with eight compare + select pairs."""
+    m = re.search(r"^(_ZN3lva13lva_step_lazyILi8ELi3E%s\S*):" % inst, asm, re.M)
+    body = asm[m.start():asm.index(".Lfunc_end", m.start())]
+    head = body[:body.index("s_barrier")]
+    # the four chunks are straight-line loads (two shared with the 4-row shape of a compact source position, two more for 8 rows)
+    assert len(re.findall(r"^\s+global_load_dwordx4", head, re.M)) == 4
+    # (the loop that was there held ONE such load)
+    assert body.count("v_min3_u32") >= 6                                     # three per merge loop (8 lists, 2 lists)
